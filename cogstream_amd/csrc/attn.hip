@@ -1,0 +1,438 @@
+// Fused attention for the ViT encoder (per-frame block-diagonal, hd 72) and the Qwen2
+// prefill (causal GQA, hd 128).
+//
+// Replaces: flash_attn_varlen_func (model/modeling_videollama3_encoder.py:309-312), the
+// eager softmax(QK^T/sqrt(d) + mask) path (:257-271, "global + same-frame bias" mode,
+// parity only) and transformers' Qwen2 attention (GQA repeat_kv, causal mask, fp32 softmax).
+//
+// bf16 kernel (gfx950):
+//   * one workgroup = 4 waves = 128 query rows of one (segment, head); K/V tiles of 64 keys
+//     are register-staged (global loads issued before the compute of the previous tile,
+//     LDS write after it) into one LDS buffer;
+//   * scores are computed TRANSPOSED, S^T[key][q] = K.Q^T (K rows are the MFMA A operand),
+//     with the key rows of each 32-key half permuted so that the S^T accumulator of a lane
+//     is exactly the B-operand fragment of the following O^T[d][q] = V^T.P^T product: P never
+//     leaves registers; the softmax row statistics are per-lane scalars (q = lane&15) and
+//     need two cross-lane exchanges per tile;
+//   * V stays row-major [key][d] in LDS and is consumed column-major through the hardware
+//     transpose read ds_read_b64_tr_b16; K rows are 256 B with a chunk XOR so the
+//     ds_read_b128 fragment reads are bank-conflict free;
+//   * head dim 72 is zero-padded to 96 for QK^T (3 k-steps) and 80 for PV (5 d-tiles).
+// fp32 / generic kernel: one wave per (query row, head), two passes; parity mode only.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct AttnArgs {
+    const void* Q; const void* K; const void* V; void* O;
+    long ldq, ldk, ldv, ldo;        // elements
+    const int* cu;                  // [nseg+1] or null
+    const int* row_lo;              // bias mode: same-segment key range per query row
+    const int* row_hi;
+    int q_len, kv_len;
+    int hq, hkv;
+    float scale_log2;               // softmax scale * log2(e)
+    float bias_log2;                // additive same-segment bias * log2(e)
+    int q_pos0;                     // causal: key j visible to query i iff j <= i + q_pos0
+    int causal;
+    int nsplit;                     // >1: keys split over blocks, partials go to part_o/part_ml
+    int gqa_pack;                   // decode: the q-heads of one kv head are the 16 query columns
+    float* part_o;                  // [nsplit][q_len][hq][HD] unnormalised
+    float* part_ml;                 // [nsplit][q_len][hq][2]  (running max (log2 domain), sum)
+};
+
+__device__ __forceinline__ int k_swz(int row) { return (row & 3) | (((row >> 3) & 3) << 2); }
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
+    constexpr int KS = (HD + 31) / 32;        // QK^T k-steps
+    constexpr int DT = (HD + 15) / 16;        // PV d-tiles
+    constexpr int CH = HD / 8;                // 16-byte chunks per K/V row
+    constexpr int NCH = 64 * CH;
+    constexpr int PER = (NCH + 255) / 256;
+    constexpr int VS = (HD > 80) ? 288 : 160; // V row stride, == 32*odd bytes
+    constexpr int VG = 8 * VS + 128;          // stride of a group of 8 V rows
+    constexpr int K_LDS = 64 * 256;
+    __shared__ __attribute__((aligned(16))) char smem[K_LDS + 8 * VG];
+    char* const Ks = smem;
+    char* const Vs = smem + K_LDS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int seg = blockIdx.z;
+    const int gsz = p.hq / p.hkv;
+    const int kvh = p.gqa_pack ? blockIdx.y : blockIdx.y / gsz;
+    const int split = blockIdx.x % p.nsplit;
+
+    int qs = 0, qe = p.q_len, ks = 0, ke = p.kv_len;
+    if (p.cu) { qs = p.cu[seg]; qe = p.cu[seg + 1]; ks = qs; ke = qe; }
+    const int q0 = qs + (blockIdx.x / p.nsplit) * 128;
+    if (q0 >= qe) return;
+
+    const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q);
+    const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K);
+    const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.V);
+
+    // zero the pad columns once (staging never writes them)
+    if (HD % 32 != 0) {
+        for (int id = tid; id < 64 * (16 - CH); id += 256) {
+            const int row = id / (16 - CH), c = CH + id % (16 - CH);
+            *reinterpret_cast<u32x4*>(Ks + row * 256 + ((c ^ k_swz(row)) << 4)) = u32x4{0, 0, 0, 0};
+        }
+    }
+    if (HD % 16 != 0) {
+        for (int row = tid; row < 64; row += 256)
+            *reinterpret_cast<u32x4*>(Vs + (row >> 3) * VG + (row & 7) * VS + CH * 16) = u32x4{0, 0, 0, 0};
+    }
+
+    // Q fragments (B operand of S^T = K.Q^T): lane (q = li, g) holds Q[q][32s + 8g + j]
+    bf16x8 qf[2][KS];
+    int qrow[2], qhead[2];
+    bool qok[2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        if (p.gqa_pack) {
+            // one query token; column li of sub-tile 0 of wave 0 is q-head kvh*gsz + li
+            qrow[qi] = q0;
+            qhead[qi] = kvh * gsz + li;
+            qok[qi] = (wid == 0 && qi == 0 && li < gsz);
+        } else {
+            qrow[qi] = q0 + wid * 32 + qi * 16 + li;
+            qhead[qi] = blockIdx.y;
+            qok[qi] = qrow[qi] < qe;
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 32 * s + 8 * g;
+            u32x4 v = {0, 0, 0, 0};
+            if (qok[qi] && k < HD)
+                v = *reinterpret_cast<const u32x4*>(Qp + (long)qrow[qi] * p.ldq + qhead[qi] * HD + k);
+            qf[qi][s] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+
+    int kend = ke;
+    if (p.causal) kend = min(ke, ks + (q0 - qs) + (p.gqa_pack ? 0 : 127) + p.q_pos0 + 1);
+    const int nt_all = (kend - ks + 63) / 64;
+    const int t_begin = (int)((long)nt_all * split / p.nsplit);
+    const int nt = (int)((long)nt_all * (split + 1) / p.nsplit);
+
+    f32x4 oacc[DT][2];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { oacc[d][0] = f32x4{0, 0, 0, 0}; oacc[d][1] = f32x4{0, 0, 0, 0}; }
+    float m_run[2] = {-INFINITY, -INFINITY};
+    float l_run[2] = {0.f, 0.f};
+
+    int blo[2] = {0, 0}, bhi[2] = {0, 0};
+    if (p.row_lo) {
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+            if (qok[qi]) { blo[qi] = p.row_lo[qrow[qi]]; bhi[qi] = p.row_hi[qrow[qi]]; }
+    }
+
+    u32x4 kreg[PER], vreg[PER];
+    auto load_tile = [&](int kt) {
+        const int kbase = ks + kt * 64;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int id = tid + i * 256;
+            kreg[i] = u32x4{0, 0, 0, 0};
+            vreg[i] = u32x4{0, 0, 0, 0};
+            if (id < NCH) {
+                const int row = id / CH, c = id % CH;
+                const int key = kbase + row;
+                if (key < ke) {
+                    kreg[i] = *reinterpret_cast<const u32x4*>(Kp + (long)key * p.ldk + kvh * HD + c * 8);
+                    vreg[i] = *reinterpret_cast<const u32x4*>(Vp + (long)key * p.ldv + kvh * HD + c * 8);
+                }
+            }
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int id = tid + i * 256;
+            if (id < NCH) {
+                const int row = id / CH, c = id % CH;
+                *reinterpret_cast<u32x4*>(Ks + row * 256 + ((c ^ k_swz(row)) << 4)) = kreg[i];
+                *reinterpret_cast<u32x4*>(Vs + (row >> 3) * VG + (row & 7) * VS + c * 16) = vreg[i];
+            }
+        }
+    };
+
+    // per-lane LDS addresses
+    // K fragment (A operand): row r = li -> key 32u + 8(r>>2) + 4t + (r&3), chunk 4s + g
+    const int krow0 = 8 * (li >> 2) + (li & 3);
+    // V transposed read: lane i of a 16-lane group supplies row k0 + (i>>2), cols d0 + 4(i&3)
+    const int vrow_off = g * VG + (li >> 2) * VS + (li & 3) * 8;
+
+    if (t_begin < nt) load_tile(t_begin);
+    for (int kt = t_begin; kt < nt; ++kt) {
+        __syncthreads();
+        write_tile();
+        __syncthreads();
+        if (kt + 1 < nt) load_tile(kt + 1);
+
+        const int kbase = ks + kt * 64;
+        f32x4 sacc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sacc[i][0] = f32x4{0, 0, 0, 0}; sacc[i][1] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int ut = 0; ut < 4; ++ut) {
+            const int krow = 32 * (ut >> 1) + 4 * (ut & 1) + krow0;
+            const int ksw = k_swz(krow);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + krow * 256 + (((4 * s + g) ^ ksw) << 4));
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi)
+                    sacc[ut][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, kf), qf[qi][s], sacc[ut][qi], 0, 0, 0);
+            }
+        }
+
+        // online softmax; lane holds keys kbase + 32u + 8g + 4t + reg of query column li
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            const int qloc = qrow[qi] - qs;
+            float sv[4][4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kbase + 32 * (ut >> 1) + 8 * g + 4 * (ut & 1) + r;
+                    bool valid = key < ke;
+                    if (p.causal) valid = valid && (key - ks) <= qloc + p.q_pos0;
+                    float s = sacc[ut][qi][r] * p.scale_log2;
+                    if (p.row_lo && key >= blo[qi] && key < bhi[qi]) s += p.bias_log2;
+                    s = valid ? s : -INFINITY;
+                    sv[ut][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qi], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = exp2f(m_run[qi] - m_use);
+            float psum = 0.f;
+#pragma unroll
+            for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2f(sv[ut][r] - m_use);
+                    sv[ut][r] = pv;
+                    psum += pv;
+                }
+            l_run[qi] = l_run[qi] * alpha + psum;
+            m_run[qi] = m_new;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) oacc[d][qi] *= alpha;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                u32x4 w;
+                w[0] = pack_bf2(sv[2 * u][0], sv[2 * u][1]);
+                w[1] = pack_bf2(sv[2 * u][2], sv[2 * u][3]);
+                w[2] = pack_bf2(sv[2 * u + 1][0], sv[2 * u + 1][1]);
+                w[3] = pack_bf2(sv[2 * u + 1][2], sv[2 * u + 1][3]);
+                pf[u][qi] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+
+        // O^T[d][q] += V^T[d][key] . P^T[key][q]
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const char* va = Vs + u * 4 * VG + vrow_off + d * 32;
+                const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) i16x4*)(va));
+                const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) i16x4*)(va + 4 * VS));
+                u32x4 w;
+                u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                w[0] = l2[0]; w[1] = l2[1]; w[2] = h2[0]; w[3] = h2[1];
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+                for (int qi = 0; qi < 2; ++qi)
+                    oacc[d][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][qi], oacc[d][qi], 0, 0, 0);
+            }
+        }
+    }
+
+    bf16_t* Op = reinterpret_cast<bf16_t*>(p.O);
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        float l = l_run[qi];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (!qok[qi]) continue;
+        if (p.nsplit > 1) {
+            const long slot = ((long)split * p.q_len + qrow[qi]) * p.hq + qhead[qi];
+            if (g == 0) { p.part_ml[slot * 2] = m_run[qi]; p.part_ml[slot * 2 + 1] = l; }
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int dd = 16 * d + 4 * g;
+                if (dd < HD) *reinterpret_cast<f32x4*>(p.part_o + slot * HD + dd) = oacc[d][qi];
+            }
+        } else {
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int dd = 16 * d + 4 * g;
+                if (dd < HD) {
+                    f32x4 v = oacc[d][qi] * inv;
+                    st4_f<bf16_t>(Op + (long)qrow[qi] * p.ldo + qhead[qi] * HD + dd, v);
+                }
+            }
+        }
+    }
+}
+
+// combine the key-split partials: one wave per (query row, head)
+__global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ part_o,
+                                                          const float* __restrict__ part_ml, int nsplit, int q_len,
+                                                          int hq, int HD, bf16_t* __restrict__ O, long ldo) {
+    const int lane = threadIdx.x;
+    const int q = blockIdx.x, h = blockIdx.y;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[(((long)s * q_len + q) * hq + h) * 2]);
+    float L = 0.f;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+        const long slot = ((long)s * q_len + q) * hq + h;
+        const float m = part_ml[slot * 2];
+        const float w = (m == -INFINITY) ? 0.f : exp2f(m - M);
+        L += part_ml[slot * 2 + 1] * w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int d = lane + 64 * e;
+            if (d < HD) o[e] += part_o[slot * HD + d] * w;
+        }
+    }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int d = lane + 64 * e;
+        if (d < HD) O[(long)q * ldo + h * HD + d] = f2bf(o[e] * inv);
+    }
+}
+
+// Generic reference-precision kernel: one wave per (query row, head); fp32 math.
+template <typename T>
+__global__ __launch_bounds__(64) void attn_rowwise_kernel(AttnArgs p, int HD, int nseg) {
+    const int lane = threadIdx.x;
+    const int q = blockIdx.x, head = blockIdx.y;
+    const int kvh = head / (p.hq / p.hkv);
+    int qs = 0, ks = 0, ke = p.kv_len;
+    if (p.cu) {
+        // binary search the segment of row q
+        int lo = 0, hi = nseg;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.cu[mid] <= q) lo = mid; else hi = mid; }
+        qs = p.cu[lo]; ks = qs; ke = p.cu[lo + 1];
+    }
+    const T* Qp = reinterpret_cast<const T*>(p.Q) + (long)q * p.ldq + head * HD;
+    const T* Kp = reinterpret_cast<const T*>(p.K) + kvh * HD;
+    const T* Vp = reinterpret_cast<const T*>(p.V) + kvh * HD;
+    __shared__ float qsh[256];
+    for (int d = lane; d < HD; d += 64) qsh[d] = ld_f<T>(Qp + d);
+    __syncthreads();
+    int kend = ke;
+    if (p.causal) kend = min(ke, ks + (q - qs) + p.q_pos0 + 1);
+    int blo = 0, bhi = 0;
+    if (p.row_lo) { blo = p.row_lo[q]; bhi = p.row_hi[q]; }
+    const float LOG2E = 1.4426950408889634f;
+    const float scale = p.scale_log2 / LOG2E, bias = p.bias_log2 / LOG2E;
+    // pass 1: row max and sum
+    float m = -INFINITY, l = 0.f;
+    for (int j = ks + lane; j < kend; j += 64) {
+        float s = 0.f;
+        for (int d = 0; d < HD; ++d) s += qsh[d] * ld_f<T>(Kp + (long)j * p.ldk + d);
+        s *= scale;
+        if (p.row_lo && j >= blo && j < bhi) s += bias;
+        const float mn = fmaxf(m, s);
+        l = l * expf(m - mn) + expf(s - mn);
+        m = mn;
+    }
+    const float mall = wave_max(m);
+    l = (m == -INFINITY) ? 0.f : l * expf(m - mall);
+    const float lall = wave_sum(l);
+    const float inv = lall > 0.f ? 1.f / lall : 0.f;
+    // pass 2: O[d] = sum_j p_j V[j][d]; lanes own d, d+64, ...
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = ks; j0 < kend; j0 += 64) {
+        const int j = j0 + lane;
+        float pj = 0.f;
+        if (j < kend) {
+            float s = 0.f;
+            for (int d = 0; d < HD; ++d) s += qsh[d] * ld_f<T>(Kp + (long)j * p.ldk + d);
+            s *= scale;
+            if (p.row_lo && j >= blo && j < bhi) s += bias;
+            pj = expf(s - mall) * inv;
+        }
+        const int cnt = min(64, kend - j0);
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float pb = __shfl(pj, jj, 64);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = lane + 64 * e;
+                if (d < HD) o[e] += pb * ld_f<T>(Vp + (long)(j0 + jj) * p.ldv + d);
+            }
+        }
+    }
+    T* Op = reinterpret_cast<T*>(p.O) + (long)q * p.ldo + head * HD;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int d = lane + 64 * e;
+        if (d < HD) st_f<T>(Op + d, o[e]);
+    }
+}
+
+}  // namespace
+
+int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
+    if (a.q_len <= 0 || a.hq <= 0 || a.hkv <= 0 || a.hq % a.hkv != 0) return COGS_E_INVALID;
+    if (a.head_dim > 256 || a.head_dim % 8 != 0) return COGS_E_UNSUPPORTED;
+    AttnArgs p;
+    p.Q = a.Q; p.K = a.K; p.V = a.V; p.O = a.O;
+    p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo;
+    p.cu = a.cu_seqlens; p.row_lo = a.row_lo; p.row_hi = a.row_hi;
+    p.q_len = a.q_len; p.kv_len = a.kv_len; p.hq = a.hq; p.hkv = a.hkv;
+    const float LOG2E = 1.4426950408889634f;
+    p.scale_log2 = a.scale * LOG2E; p.bias_log2 = a.bias * LOG2E;
+    p.q_pos0 = a.q_pos0; p.causal = a.causal;
+    const int nseg = a.cu_seqlens ? a.nseg : 1;
+    p.nsplit = 1; p.gqa_pack = 0; p.part_o = nullptr; p.part_ml = nullptr;
+    if (a.dtype == COGS_DT_BF16 && !a.force_rowwise && (a.head_dim == 72 || a.head_dim == 128)) {
+        if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) return COGS_E_INVALID;
+        const int max_len = a.cu_seqlens ? a.max_seqlen : a.q_len;
+        int qtiles = (max_len + 127) / 128;
+        int gy = a.hq;
+        if (a.nsplit > 1) {
+            if (a.cu_seqlens || a.row_lo) return COGS_E_UNSUPPORTED;
+            const size_t need = (size_t)a.nsplit * a.q_len * a.hq * (a.head_dim + 2) * sizeof(float);
+            if (!a.ws || a.ws_bytes < need) return COGS_E_WORKSPACE;
+            p.nsplit = a.nsplit;
+            p.part_o = (float*)a.ws;
+            p.part_ml = p.part_o + (size_t)a.nsplit * a.q_len * a.hq * a.head_dim;
+        }
+        if (a.q_len == 1 && a.hq / a.hkv <= 16 && !a.cu_seqlens) { p.gqa_pack = 1; gy = a.hkv; }
+        dim3 grid(qtiles * p.nsplit, gy, nseg);
+        if (a.head_dim == 72)
+            hipLaunchKernelGGL(attn_fwd_bf16_kernel<72>, grid, dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL(attn_fwd_bf16_kernel<128>, grid, dim3(256), 0, st, p);
+        if (p.nsplit > 1)
+            hipLaunchKernelGGL(attn_combine_kernel, dim3(a.q_len, a.hq), dim3(64), 0, st, p.part_o, p.part_ml, p.nsplit,
+                               a.q_len, a.hq, a.head_dim, (bf16_t*)a.O, a.ldo);
+        return COGS_LAUNCH_CHECK();
+    }
+    dim3 grid(a.q_len, a.hq);
+    if (a.dtype == COGS_DT_BF16)
+        hipLaunchKernelGGL(attn_rowwise_kernel<bf16_t>, grid, dim3(64), 0, st, p, a.head_dim, nseg);
+    else
+        hipLaunchKernelGGL(attn_rowwise_kernel<float>, grid, dim3(64), 0, st, p, a.head_dim, nseg);
+    return COGS_LAUNCH_CHECK();
+}

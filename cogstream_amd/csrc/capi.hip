@@ -1,0 +1,533 @@
+// C-ABI layer of libcogs_hip.so (see include/cogs.h): argument checking, workspace carving and
+// the per-model launch sequences (ViT encoder, projector, Qwen2 forward). No torch types, no
+// exceptions, no device synchronisation.
+#include "../../include/cogs.h"
+#include "common.h"
+#include "kernels.h"
+
+#include <math.h>
+#include <new>
+#include <string.h>
+#include <vector>
+
+struct cogs_ctx {
+    int device = 0;
+    // ViT
+    bool vit_ok = false;
+    cogs_vit_weights vit{};
+    std::vector<cogs_vit_layer> vit_layers;
+    float* vit_inv_freq = nullptr;  // device [head_dim/4]
+    int vit_nfreq = 0;
+    // projector
+    bool proj_ok = false;
+    cogs_proj_weights proj{};
+    // LLM
+    bool llm_ok = false;
+    cogs_llm_weights llm{};
+    std::vector<cogs_llm_layer> llm_layers;
+    float* llm_inv_freq = nullptr;  // device [head_dim/2]
+    // host staging kept alive across async copies
+    std::vector<int32_t> h_cu, h_lo, h_hi;
+};
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+inline int esize(int dtype) { return dtype == COGS_DT_BF16 ? 2 : 4; }
+
+struct Carver {
+    char* base; size_t off = 0; size_t cap;
+    Carver(void* p, size_t c) : base((char*)p), cap(c) {}
+    void* take(size_t bytes) {
+        const size_t o = off;
+        off = align_up(off + bytes);
+        return base ? base + o : nullptr;
+    }
+};
+
+#define COGS_TRY(x)                      \
+    do {                                 \
+        const int _rc = (x);             \
+        if (_rc != COGS_OK) return _rc;  \
+    } while (0)
+
+CogsGemm to_gemm(const cogs_gemm_desc* d) {
+    CogsGemm g;
+    g.dtype = d->dtype;
+    g.A = d->A; g.lda = d->lda; g.W = d->W; g.ldw = d->ldw; g.C = d->C; g.ldc = d->ldc;
+    g.bias = d->bias; g.residual = d->residual; g.ldr = d->ldr;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.act = d->act; g.out_f32 = d->out_f32;
+    g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.rope_cols = d->rope_cols; g.head_dim = d->head_dim;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cogs_status_string(cogs_status s) {
+    switch (s) {
+        case COGS_OK: return "ok";
+        case COGS_E_INVALID: return "invalid argument";
+        case COGS_E_HIP: return "HIP runtime error";
+        case COGS_E_UNSUPPORTED: return "unsupported configuration";
+        case COGS_E_WORKSPACE: return "workspace missing or too small";
+        default: return "unknown status";
+    }
+}
+
+const char* cogs_version(void) { return "cogstream_amd 0.1 (gfx950)"; }
+
+cogs_status cogs_create(int device, cogs_handle* out) {
+    if (!out) return COGS_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return COGS_E_HIP;
+    cogs_ctx* c = new (std::nothrow) cogs_ctx();
+    if (!c) return COGS_E_HIP;
+    c->device = device;
+    *out = c;
+    return COGS_OK;
+}
+
+cogs_status cogs_destroy(cogs_handle h) {
+    if (!h) return COGS_OK;
+    if (h->vit_inv_freq) (void)hipFree(h->vit_inv_freq);
+    if (h->llm_inv_freq) (void)hipFree(h->llm_inv_freq);
+    delete h;
+    return COGS_OK;
+}
+
+// ---------------------------------------------------------------- operator level
+
+cogs_status cogs_gemm(cogs_stream stream, const cogs_gemm_desc* d) {
+    if (!d || !d->A || !d->W || !d->C) return COGS_E_INVALID;
+    return cogs_k_gemm((hipStream_t)stream, to_gemm(d));
+}
+
+cogs_status cogs_attention(cogs_stream stream, const cogs_attn_desc* d) {
+    if (!d || !d->Q || !d->K || !d->V || !d->O) return COGS_E_INVALID;
+    CogsAttn a;
+    a.dtype = d->dtype; a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
+    a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
+    a.cu_seqlens = d->cu_seqlens; a.nseg = d->nseg; a.max_seqlen = d->max_seqlen;
+    a.row_lo = d->row_lo; a.row_hi = d->row_hi; a.bias = d->bias;
+    a.q_len = d->q_len; a.kv_len = d->kv_len; a.hq = d->hq; a.hkv = d->hkv; a.head_dim = d->head_dim;
+    a.scale = d->scale; a.causal = d->causal; a.q_pos0 = d->q_pos0; a.force_rowwise = d->force_rowwise;
+    a.nsplit = d->nsplit > 1 ? d->nsplit : 1; a.ws = d->ws; a.ws_bytes = d->ws_bytes;
+    return cogs_k_attention((hipStream_t)stream, a);
+}
+
+cogs_status cogs_layernorm(cogs_stream stream, int dtype, const void* x, void* y, const void* gamma, const void* beta,
+                           int rows, int H, float eps) {
+    return cogs_k_layernorm((hipStream_t)stream, dtype, x, y, gamma, beta, rows, H, eps);
+}
+cogs_status cogs_rmsnorm(cogs_stream stream, int dtype, const void* x, void* y, const void* gamma, int rows, int H,
+                         float eps) {
+    return cogs_k_rmsnorm((hipStream_t)stream, dtype, x, y, gamma, rows, H, eps);
+}
+cogs_status cogs_ln_merge(cogs_stream stream, int dtype, const void* x, void* y, const void* gamma, const void* beta,
+                          int out_rows, int group, int H, float eps) {
+    return cogs_k_ln_merge((hipStream_t)stream, dtype, x, y, gamma, beta, out_rows, group, H, eps);
+}
+
+cogs_status cogs_pixdiff_mask(cogs_stream stream, int dtype, const void* pix, int t, int P, int E, float thr,
+                              int min_tokens, const uint8_t* minor, uint8_t* mask) {
+    if (!pix || !mask) return COGS_E_INVALID;
+    COGS_TRY(cogs_k_pixdiff_mask((hipStream_t)stream, dtype, pix, t, P, E, thr, min_tokens, mask));
+    return cogs_k_mask_fix((hipStream_t)stream, mask, t, P, min_tokens, minor);
+}
+cogs_status cogs_frame_mean_to_slot0(cogs_stream stream, int dtype, void* feats, int P, int D, const int32_t* frames,
+                                     int n_frames) {
+    return cogs_k_frame_mean_to_slot0((hipStream_t)stream, dtype, feats, P, D, frames, n_frames);
+}
+cogs_status cogs_gather_rows(cogs_stream stream, int dtype, const void* ta, const void* tb, const int64_t* idx,
+                             void* out, int rows, int D) {
+    return cogs_k_gather_rows((hipStream_t)stream, dtype, ta, tb, idx, out, rows, D);
+}
+cogs_status cogs_mean_rows(cogs_stream stream, int dtype, const void* x, int64_t ldx, int rows, int D, float* out) {
+    return cogs_k_mean_rows((hipStream_t)stream, dtype, x, ldx, rows, D, out);
+}
+cogs_status cogs_cosine(cogs_stream stream, const float* a, const float* b, int n, int D, float* out) {
+    return cogs_k_cosine((hipStream_t)stream, a, b, n, D, out);
+}
+
+cogs_status cogs_kmeans_workspace_bytes(int T, int64_t PD, int K, size_t* bytes) {
+    if (!bytes || T <= 0 || PD <= 0 || K <= 0) return COGS_E_INVALID;
+    *bytes = align_up(cogs_k_kmeans_ws(T, PD, K, nullptr));
+    return COGS_OK;
+}
+cogs_status cogs_kmeans_sqdist(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD,
+                               const float* centres, const int32_t* centre_rows, int K, float* dist2, void* ws,
+                               size_t ws_bytes) {
+    int ns = 0;
+    const size_t need = cogs_k_kmeans_ws(T, PD, K, &ns);
+    if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
+    if (!centres && !centre_rows) return COGS_E_INVALID;
+    return cogs_k_kmeans_sqdist((hipStream_t)stream, dtype, feats, T, PD, centres, centre_rows, K, (float*)ws, ns, dist2);
+}
+cogs_status cogs_kmeans_assign(cogs_stream stream, const float* dist2, const float* ts, const float* centre_ts, int T,
+                               int K, float alpha, int64_t* assign, int32_t* counts) {
+    return cogs_k_kmeans_assign((hipStream_t)stream, dist2, ts, centre_ts, T, K, alpha, assign, counts);
+}
+cogs_status cogs_kmeans_update(cogs_stream stream, int dtype, const void* feats, const float* ts, int T, int64_t PD,
+                               int K, const int64_t* assign, const int32_t* reseed_rows, float* centres,
+                               float* centre_ts, float* shift_out, void* ws, size_t ws_bytes) {
+    const size_t need = cogs_k_kmeans_ws(T, PD, K, nullptr);
+    if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
+    return cogs_k_kmeans_update((hipStream_t)stream, dtype, feats, ts, T, PD, K, assign, reseed_rows, centres,
+                                centre_ts, (float*)ws, cogs_k_kmeans_update_blocks(PD), shift_out);
+}
+cogs_status cogs_pack_rows(cogs_stream stream, int in_dtype, int out_dtype, const void* in, int64_t ld_in, void* out,
+                           int64_t ld_out, int rows, int cols_in, int cols_out) {
+    return cogs_k_pack_rows((hipStream_t)stream, in_dtype, out_dtype, in, ld_in, out, ld_out, rows, cols_in, cols_out);
+}
+
+cogs_status cogs_argmax(cogs_stream stream, const float* logits, int n, int64_t* out, void* ws) {
+    if (!ws) return COGS_E_WORKSPACE;
+    return cogs_k_argmax((hipStream_t)stream, logits, n, out, (float*)ws);
+}
+cogs_status cogs_logits_process(cogs_stream stream, float* logits, int n, const int64_t* prev, int n_prev,
+                                float repetition_penalty, const int32_t* allowed, int n_allowed, float temperature,
+                                float* tmp) {
+    if (n_prev > 0 && !tmp) return COGS_E_WORKSPACE;
+    return cogs_k_logits_process((hipStream_t)stream, logits, n, prev, n_prev, repetition_penalty, allowed, n_allowed,
+                                 temperature, tmp);
+}
+cogs_status cogs_topk(cogs_stream stream, const float* logits, int n, int top_k, float* topk_val, int32_t* topk_idx,
+                      float* ws) {
+    if (!ws) return COGS_E_WORKSPACE;
+    return cogs_k_topk((hipStream_t)stream, logits, n, top_k, topk_val, topk_idx, ws);
+}
+
+// ---------------------------------------------------------------- vision encoder
+
+cogs_status cogs_vit_load(cogs_handle h, const cogs_vit_weights* w) {
+    if (!h || !w || !w->layer || w->layers <= 0 || w->heads <= 0) return COGS_E_INVALID;
+    if (w->hidden % w->heads || (w->hidden / w->heads) % 4) return COGS_E_INVALID;
+    const int slab = w->dtype == COGS_DT_BF16 ? 64 : 32;
+    if (w->hidden % slab || w->inter_pad % slab || w->patch_pad % slab || w->inter_pad % 4) return COGS_E_INVALID;
+    h->vit = *w;
+    h->vit_layers.assign(w->layer, w->layer + w->layers);
+    h->vit.layer = h->vit_layers.data();
+    // VisionRotaryEmbedding(head_dim // 2): inv_freq = 1 / theta^(arange(0, dim, 2)/dim), dim = head_dim/2
+    const int hd = w->hidden / w->heads;
+    const int dim = hd / 2;
+    const int nf = dim / 2;
+    std::vector<float> inv(nf);
+    for (int i = 0; i < nf; ++i) inv[i] = 1.0f / powf(10000.0f, (float)(2 * i) / (float)dim);
+    if (h->vit_inv_freq) (void)hipFree(h->vit_inv_freq);
+    if (hipMalloc(&h->vit_inv_freq, nf * sizeof(float)) != hipSuccess) return COGS_E_HIP;
+    if (hipMemcpy(h->vit_inv_freq, inv.data(), nf * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return COGS_E_HIP;
+    h->vit_nfreq = nf;
+    h->vit_ok = true;
+    return COGS_OK;
+}
+
+static size_t vit_carve(const cogs_vit_weights& w, int64_t N, int nframes, Carver& c, void** xpad, void** x, void** ln,
+                        void** big, float** rc, float** rs, int32_t** cu, int32_t** lo, int32_t** hi) {
+    const size_t es = esize(w.dtype);
+    const int hd = w.hidden / w.heads;
+    *xpad = c.take((size_t)N * w.patch_pad * es);
+    *x = c.take((size_t)N * w.hidden * es);
+    *ln = c.take((size_t)N * w.hidden * es);
+    const size_t bigcols = (size_t)(4 * w.hidden > w.inter_pad ? 4 * w.hidden : w.inter_pad);
+    *big = c.take((size_t)N * bigcols * es);  // [qkv | attn_out] then reused as the MLP hidden
+    *rc = (float*)c.take((size_t)N * (hd / 2) * sizeof(float));
+    *rs = (float*)c.take((size_t)N * (hd / 2) * sizeof(float));
+    *cu = (int32_t*)c.take((size_t)(nframes + 1) * sizeof(int32_t));
+    *lo = (int32_t*)c.take((size_t)N * sizeof(int32_t));
+    *hi = (int32_t*)c.take((size_t)N * sizeof(int32_t));
+    return c.off;
+}
+
+cogs_status cogs_vit_workspace_bytes(cogs_handle h, int64_t n_patches, size_t* bytes) {
+    if (!h || !h->vit_ok || !bytes || n_patches <= 0) return COGS_E_INVALID;
+    Carver c(nullptr, 0);
+    void *a, *b, *d, *e; float *rc, *rs; int32_t *cu, *lo, *hi;
+    // frames <= patches; size the cu_seqlens array for the worst case
+    *bytes = vit_carve(h->vit, n_patches, (int)n_patches, c, &a, &b, &d, &e, &rc, &rs, &cu, &lo, &hi);
+    return COGS_OK;
+}
+
+cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
+                            const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
+                            void* out_tokens, void* ws, size_t ws_bytes) {
+    if (!h || !h->vit_ok || !pixel_values || !grid_sizes || !merge_sizes || V <= 0 || !out_tokens) return COGS_E_INVALID;
+    const cogs_vit_weights& w = h->vit;
+    hipStream_t st = (hipStream_t)stream;
+    const int dt = w.dtype;
+    const size_t es = esize(dt);
+    const int H = w.hidden, hd = H / w.heads;
+    int64_t N = 0; int nframes = 0;
+    for (int v = 0; v < V; ++v) {
+        const int64_t t = grid_sizes[3 * v], gh = grid_sizes[3 * v + 1], gw = grid_sizes[3 * v + 2], ms = merge_sizes[v];
+        if (t <= 0 || gh <= 0 || gw <= 0 || ms <= 0 || gh % ms || gw % ms) return COGS_E_INVALID;
+        N += t * gh * gw;
+        nframes += (int)t;
+    }
+    if (N > 0x7fffffff) return COGS_E_INVALID;
+    Carver c(ws, ws_bytes);
+    void *xpad, *x, *ln, *big; float *rc, *rs; int32_t *cu, *lo, *hi;
+    const size_t need = vit_carve(w, N, nframes, c, &xpad, &x, &ln, &big, &rc, &rs, &cu, &lo, &hi);
+    if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
+    char* qkv = (char*)big;
+    char* att = qkv + (size_t)N * 3 * H * es;
+
+    // cu_seqlens (:439-440), same-frame ranges for the eager-global mode, rotary tables (:405-434)
+    h->h_cu.assign(1, 0);
+    int max_seq = 0;
+    {
+        int64_t row = 0;
+        const bool need_rows = attn_mode == COGS_ATTN_REF_EAGER_GLOBAL;
+        if (need_rows) { h->h_lo.resize(N); h->h_hi.resize(N); }
+        for (int v = 0; v < V; ++v) {
+            const int t = (int)grid_sizes[3 * v], gh = (int)grid_sizes[3 * v + 1], gw = (int)grid_sizes[3 * v + 2];
+            const int per = gh * gw;
+            if (per > max_seq) max_seq = per;
+            COGS_TRY(cogs_k_vit_rope_table(st, rc, rs, (int)row, t, gh, gw, (int)merge_sizes[v], h->vit_inv_freq, h->vit_nfreq));
+            for (int f = 0; f < t; ++f) {
+                if (need_rows)
+                    for (int r = 0; r < per; ++r) { h->h_lo[row + r] = (int32_t)row; h->h_hi[row + r] = (int32_t)(row + per); }
+                row += per;
+                h->h_cu.push_back((int32_t)row);
+            }
+        }
+        if (hipMemcpyAsync(cu, h->h_cu.data(), h->h_cu.size() * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess) return COGS_E_HIP;
+        if (need_rows) {
+            if (hipMemcpyAsync(lo, h->h_lo.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess) return COGS_E_HIP;
+            if (hipMemcpyAsync(hi, h->h_hi.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess) return COGS_E_HIP;
+        }
+    }
+
+    // patch embed: conv2d k=s=14 == GEMM over the 588-element rows (:202-210)
+    COGS_TRY(cogs_k_pack_rows(st, pix_dtype, dt, pixel_values, w.patch_dim, xpad, w.patch_pad, (int)N, w.patch_dim, w.patch_pad));
+    {
+        CogsGemm g; g.dtype = dt;
+        g.A = xpad; g.lda = w.patch_pad; g.W = w.patch_w; g.ldw = w.patch_pad; g.C = x; g.ldc = H;
+        g.bias = w.patch_b; g.M = (int)N; g.N = H; g.K = w.patch_pad;
+        COGS_TRY(cogs_k_gemm(st, g));
+    }
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int l = 0; l < w.layers; ++l) {
+        const cogs_vit_layer& L = h->vit_layers[l];
+        COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln1_g, L.ln1_b, (int)N, H, w.ln_eps));
+        {
+            CogsGemm g; g.dtype = dt;
+            g.A = ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = 3 * H;
+            g.bias = L.qkv_b; g.M = (int)N; g.N = 3 * H; g.K = H;
+            g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = 2 * H; g.head_dim = hd;
+            COGS_TRY(cogs_k_gemm(st, g));
+        }
+        {
+            CogsAttn a; a.dtype = dt;
+            a.Q = qkv; a.K = qkv + (size_t)H * es; a.V = qkv + (size_t)2 * H * es; a.O = att;
+            a.ldq = a.ldk = a.ldv = 3 * H; a.ldo = H;
+            a.q_len = (int)N; a.kv_len = (int)N; a.hq = a.hkv = w.heads; a.head_dim = hd; a.scale = scale;
+            if (attn_mode == COGS_ATTN_REF_EAGER_GLOBAL) { a.row_lo = lo; a.row_hi = hi; a.bias = 1.0f; }
+            else { a.cu_seqlens = cu; a.nseg = nframes; a.max_seqlen = max_seq; }
+            COGS_TRY(cogs_k_attention(st, a));
+        }
+        {
+            CogsGemm g; g.dtype = dt;
+            g.A = att; g.lda = H; g.W = L.o_w; g.ldw = H; g.C = x; g.ldc = H;
+            g.bias = L.o_b; g.residual = x; g.ldr = H; g.M = (int)N; g.N = H; g.K = H;
+            COGS_TRY(cogs_k_gemm(st, g));
+        }
+        COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln2_g, L.ln2_b, (int)N, H, w.ln_eps));
+        {
+            CogsGemm g; g.dtype = dt;
+            g.A = ln; g.lda = H; g.W = L.fc1_w; g.ldw = H; g.C = big; g.ldc = w.inter_pad;
+            g.bias = L.fc1_b; g.M = (int)N; g.N = w.inter_pad; g.K = H; g.act = COGS_ACT_GELU_TANH;
+            COGS_TRY(cogs_k_gemm(st, g));
+        }
+        {
+            CogsGemm g; g.dtype = dt;
+            g.A = big; g.lda = w.inter_pad; g.W = L.fc2_w; g.ldw = w.inter_pad; g.C = x; g.ldc = H;
+            g.bias = L.fc2_b; g.residual = x; g.ldr = H; g.M = (int)N; g.N = H; g.K = w.inter_pad;
+            COGS_TRY(cogs_k_gemm(st, g));
+        }
+    }
+    // post_layernorm + per-video 2x2 merge (:482-510)
+    {
+        int64_t row = 0, orow = 0;
+        for (int v = 0; v < V; ++v) {
+            const int64_t n = grid_sizes[3 * v] * grid_sizes[3 * v + 1] * grid_sizes[3 * v + 2];
+            const int grp = (int)(merge_sizes[v] * merge_sizes[v]);
+            COGS_TRY(cogs_k_ln_merge(st, dt, (char*)x + (size_t)row * H * es, (char*)out_tokens + (size_t)orow * H * es,
+                                     w.post_ln_g, w.post_ln_b, (int)(n / grp), grp, H, w.ln_eps));
+            row += n;
+            orow += n / grp;
+        }
+    }
+    return COGS_OK;
+}
+
+cogs_status cogs_proj_load(cogs_handle h, const cogs_proj_weights* w) {
+    if (!h || !w || !w->w1 || !w->w2) return COGS_E_INVALID;
+    const int slab = w->dtype == COGS_DT_BF16 ? 64 : 32;
+    if (w->in_dim % slab || w->out_dim % slab) return COGS_E_INVALID;
+    h->proj = *w;
+    h->proj_ok = true;
+    return COGS_OK;
+}
+
+cogs_status cogs_project(cogs_handle h, cogs_stream stream, const void* tokens, int M, void* out, void* ws,
+                         size_t ws_bytes) {
+    if (!h || !h->proj_ok || !tokens || !out || M <= 0) return COGS_E_INVALID;
+    const cogs_proj_weights& w = h->proj;
+    if (!ws || ws_bytes < (size_t)M * w.out_dim * esize(w.dtype)) return COGS_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    CogsGemm g; g.dtype = w.dtype;
+    g.A = tokens; g.lda = w.in_dim; g.W = w.w1; g.ldw = w.in_dim; g.C = ws; g.ldc = w.out_dim;
+    g.bias = w.b1; g.M = M; g.N = w.out_dim; g.K = w.in_dim; g.act = COGS_ACT_GELU_ERF;
+    COGS_TRY(cogs_k_gemm(st, g));
+    CogsGemm g2; g2.dtype = w.dtype;
+    g2.A = ws; g2.lda = w.out_dim; g2.W = w.w2; g2.ldw = w.out_dim; g2.C = out; g2.ldc = w.out_dim;
+    g2.bias = w.b2; g2.M = M; g2.N = w.out_dim; g2.K = w.out_dim;
+    return cogs_k_gemm(st, g2);
+}
+
+// ---------------------------------------------------------------- Qwen2
+
+cogs_status cogs_llm_load(cogs_handle h, const cogs_llm_weights* w) {
+    if (!h || !w || !w->layer || w->layers <= 0) return COGS_E_INVALID;
+    if (w->heads % w->kv_heads || w->head_dim % 8 || w->vocab % 4) return COGS_E_INVALID;
+    const int slab = w->dtype == COGS_DT_BF16 ? 64 : 32;
+    if (w->hidden % slab || w->inter % slab || (w->heads * w->head_dim) % slab) return COGS_E_INVALID;
+    h->llm = *w;
+    h->llm_layers.assign(w->layer, w->layer + w->layers);
+    h->llm.layer = h->llm_layers.data();
+    // Qwen2RotaryEmbedding: inv_freq = 1 / theta^(arange(0, hd, 2)/hd)
+    const int nf = w->head_dim / 2;
+    std::vector<float> inv(nf);
+    for (int i = 0; i < nf; ++i) inv[i] = 1.0f / powf(w->rope_theta, (float)(2 * i) / (float)w->head_dim);
+    if (h->llm_inv_freq) (void)hipFree(h->llm_inv_freq);
+    if (hipMalloc(&h->llm_inv_freq, nf * sizeof(float)) != hipSuccess) return COGS_E_HIP;
+    if (hipMemcpy(h->llm_inv_freq, inv.data(), nf * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return COGS_E_HIP;
+    h->llm_ok = true;
+    return COGS_OK;
+}
+
+static int llm_nsplit(int ctx) {
+    int n = (ctx + 1023) / 1024;
+    if (n < 1) n = 1;
+    if (n > 32) n = 32;
+    return n;
+}
+
+static size_t llm_carve(const cogs_llm_weights& w, int S, int max_ctx, Carver& c, void** x, void** ln, void** qkv,
+                        void** att, void** act, float** rc, float** rs, void** split, size_t* split_bytes) {
+    const size_t es = esize(w.dtype);
+    const int qd = (w.heads + 2 * w.kv_heads) * w.head_dim;
+    *x = c.take((size_t)S * w.hidden * es);
+    *ln = c.take((size_t)S * w.hidden * es);
+    *qkv = c.take((size_t)S * qd * es);
+    *att = c.take((size_t)S * w.heads * w.head_dim * es);
+    *act = c.take((size_t)S * w.inter * es);
+    *rc = (float*)c.take((size_t)S * (w.head_dim / 2) * sizeof(float));
+    *rs = (float*)c.take((size_t)S * (w.head_dim / 2) * sizeof(float));
+    *split_bytes = (size_t)llm_nsplit(max_ctx) * w.heads * (w.head_dim + 2) * sizeof(float);
+    *split = c.take(*split_bytes);
+    return c.off;
+}
+
+cogs_status cogs_llm_workspace_bytes(cogs_handle h, int max_tokens, int max_context, size_t* bytes) {
+    if (!h || !h->llm_ok || !bytes || max_tokens <= 0) return COGS_E_INVALID;
+    Carver c(nullptr, 0);
+    void *a, *b, *d, *e, *f, *sp; float *rc, *rs; size_t sb;
+    *bytes = llm_carve(h->llm, max_tokens, max_context, c, &a, &b, &d, &e, &f, &rc, &rs, &sp, &sb);
+    return COGS_OK;
+}
+
+cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embeds, int S, cogs_kv* kv,
+                             float* last_logits, float* pooled_mean, void* hidden_out, void* ws, size_t ws_bytes) {
+    if (!h || !h->llm_ok || !embeds || S <= 0) return COGS_E_INVALID;
+    const cogs_llm_weights& w = h->llm;
+    hipStream_t st = (hipStream_t)stream;
+    const int dt = w.dtype;
+    const size_t es = esize(dt);
+    const int H = w.hidden, hd = w.head_dim, kvd = w.kv_heads * hd, qd_q = w.heads * hd, qd = qd_q + 2 * kvd;
+    const int pos0 = kv ? kv->len : 0;
+    const int ctx = pos0 + S;
+    if (kv && (!kv->k || !kv->v || ctx > kv->max_len)) return COGS_E_INVALID;
+    Carver c(ws, ws_bytes);
+    void *x, *ln, *qkv, *att, *act, *split; float *rc, *rs; size_t split_bytes;
+    const size_t need = llm_carve(w, S, ctx, c, &x, &ln, &qkv, &att, &act, &rc, &rs, &split, &split_bytes);
+    if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
+
+    if (hipMemcpyAsync(x, embeds, (size_t)S * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return COGS_E_HIP;
+    COGS_TRY(cogs_k_llm_rope_table(st, rc, rs, nullptr, pos0, S, h->llm_inv_freq, hd / 2));
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int l = 0; l < w.layers; ++l) {
+        const cogs_llm_layer& L = h->llm_layers[l];
+        COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.in_ln, S, H, w.rms_eps));
+        {
+            CogsGemm g; g.dtype = dt;
+            g.A = ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = qd;
+            g.bias = L.qkv_b; g.M = S; g.N = qd; g.K = H;
+            g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = qd_q + kvd; g.head_dim = hd;
+            COGS_TRY(cogs_k_gemm(st, g));
+        }
+        const char* kp = (const char*)qkv + (size_t)qd_q * es;
+        const char* vp = kp + (size_t)kvd * es;
+        long ldkv = qd;
+        if (kv) {
+            char* kc = (char*)kv->k + ((size_t)l * kv->max_len) * kvd * es;
+            char* vc = (char*)kv->v + ((size_t)l * kv->max_len) * kvd * es;
+            COGS_TRY(cogs_k_copy_cols(st, dt, kp, qd, kc + (size_t)pos0 * kvd * es, kvd, S, kvd));
+            COGS_TRY(cogs_k_copy_cols(st, dt, vp, qd, vc + (size_t)pos0 * kvd * es, kvd, S, kvd));
+            kp = kc; vp = vc; ldkv = kvd;
+        }
+        {
+            CogsAttn a; a.dtype = dt;
+            a.Q = qkv; a.K = kp; a.V = vp; a.O = att;
+            a.ldq = qd; a.ldk = ldkv; a.ldv = ldkv; a.ldo = qd_q;
+            a.q_len = S; a.kv_len = ctx; a.hq = w.heads; a.hkv = w.kv_heads; a.head_dim = hd; a.scale = scale;
+            a.causal = 1; a.q_pos0 = pos0;
+            if (S == 1 && dt == COGS_DT_BF16 && hd == 128) {
+                a.nsplit = llm_nsplit(ctx); a.ws = split; a.ws_bytes = split_bytes;
+            }
+            COGS_TRY(cogs_k_attention(st, a));
+        }
+        {
+            CogsGemm g; g.dtype = dt;
+            g.A = att; g.lda = qd_q; g.W = L.o_w; g.ldw = qd_q; g.C = x; g.ldc = H;
+            g.residual = x; g.ldr = H; g.M = S; g.N = H; g.K = qd_q;
+            COGS_TRY(cogs_k_gemm(st, g));
+        }
+        COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.post_ln, S, H, w.rms_eps));
+        {
+            CogsGemm g; g.dtype = dt;
+            g.A = ln; g.lda = H; g.W = L.gu_w; g.ldw = H; g.C = act; g.ldc = w.inter;
+            g.M = S; g.N = 2 * w.inter; g.K = H; g.act = COGS_ACT_SWIGLU;
+            COGS_TRY(cogs_k_gemm(st, g));
+        }
+        {
+            CogsGemm g; g.dtype = dt;
+            g.A = act; g.lda = w.inter; g.W = L.down_w; g.ldw = w.inter; g.C = x; g.ldc = H;
+            g.residual = x; g.ldr = H; g.M = S; g.N = H; g.K = w.inter;
+            COGS_TRY(cogs_k_gemm(st, g));
+        }
+    }
+    if (kv) kv->len = ctx;
+    const bool need_all = pooled_mean || hidden_out;
+    if (need_all) {
+        void* hn = hidden_out ? hidden_out : ln;
+        COGS_TRY(cogs_k_rmsnorm(st, dt, x, hn, w.final_norm, S, H, w.rms_eps));
+        if (pooled_mean) COGS_TRY(cogs_k_mean_rows(st, dt, hn, H, S, H, pooled_mean));
+        if (last_logits) {
+            CogsGemm g; g.dtype = dt;
+            g.A = (char*)hn + (size_t)(S - 1) * H * es; g.lda = H; g.W = w.lm_head; g.ldw = H; g.C = last_logits;
+            g.ldc = w.vocab; g.M = 1; g.N = w.vocab; g.K = H; g.out_f32 = 1;
+            COGS_TRY(cogs_k_gemm(st, g));
+        }
+    } else if (last_logits) {
+        COGS_TRY(cogs_k_rmsnorm(st, dt, (char*)x + (size_t)(S - 1) * H * es, ln, w.final_norm, 1, H, w.rms_eps));
+        CogsGemm g; g.dtype = dt;
+        g.A = ln; g.lda = H; g.W = w.lm_head; g.ldw = H; g.C = last_logits; g.ldc = w.vocab;
+        g.M = 1; g.N = w.vocab; g.K = H; g.out_f32 = 1;
+        COGS_TRY(cogs_k_gemm(st, g));
+    }
+    return COGS_OK;
+}
+
+}  // extern "C"

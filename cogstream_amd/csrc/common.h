@@ -1,0 +1,145 @@
+// Shared device helpers for the cogstream_amd HIP kernels (gfx950 / CDNA4 only).
+//
+// Conventions used by every kernel in this directory:
+//   * wavefront = 64 lanes, workgroups are multiples of 64 threads;
+//   * bf16 tensors are passed as raw 16-bit patterns (bf16_t), converted with a
+//     plain cast so that hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even,
+//     NaN stays NaN);
+//   * all reductions use a fixed order so results are reproducible run to run.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define COGS_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t b) {
+    return __uint_as_float(((uint32_t)b) << 16);
+}
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+// pack two floats into one dword of two bf16 (lo in bits 0..15)
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// element load/store helpers templated on the storage type (bf16_t or float)
+template <typename T> __device__ __forceinline__ float ld_f(const T* p);
+template <> __device__ __forceinline__ float ld_f<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float ld_f<float>(const float* p) { return *p; }
+template <typename T> __device__ __forceinline__ void st_f(T* p, float v);
+template <> __device__ __forceinline__ void st_f<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void st_f<float>(float* p, float v) { *p = v; }
+
+// load 4 consecutive elements as floats (8-byte / 16-byte aligned)
+template <typename T> __device__ __forceinline__ f32x4 ld4_f(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4_f<bf16_t>(const bf16_t* p) {
+    u32x2 w = *reinterpret_cast<const u32x2*>(p);
+    f32x4 r = {bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
+    return r;
+}
+template <> __device__ __forceinline__ f32x4 ld4_f<float>(const float* p) {
+    return *reinterpret_cast<const f32x4*>(p);
+}
+template <typename T> __device__ __forceinline__ void st4_f(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4_f<bf16_t>(bf16_t* p, f32x4 v) {
+    u32x2 w;
+    w[0] = pack_bf2(v[0], v[1]);
+    w[1] = pack_bf2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(p) = w;
+}
+template <> __device__ __forceinline__ void st4_f<float>(float* p, f32x4 v) {
+    *reinterpret_cast<f32x4*>(p) = v;
+}
+
+// load 8 consecutive elements as floats (bf16: one 16-B load, float: two)
+template <typename T> __device__ __forceinline__ void ld8_f(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void ld8_f<bf16_t>(const bf16_t* p, float (&o)[8]) {
+    u32x4 w = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[2 * i] = bf_lo(w[i]);
+        o[2 * i + 1] = bf_hi(w[i]);
+    }
+}
+template <> __device__ __forceinline__ void ld8_f<float>(const float* p, float (&o)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[i] = a[i];
+        o[4 + i] = b[i];
+    }
+}
+template <typename T> __device__ __forceinline__ void st8_f(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8_f<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<u32x4*>(p) = w;
+}
+template <> __device__ __forceinline__ void st8_f<float>(float* p, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]};
+    f32x4 b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+// 64-lane butterfly reductions (fixed order -> deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// activations (fp32)
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))  (ACT2FN["gelu_pytorch_tanh"])
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// status codes shared with include/cogs.h
+#define COGS_OK 0
+#define COGS_E_INVALID (-1)
+#define COGS_E_HIP (-2)
+#define COGS_E_UNSUPPORTED (-3)
+#define COGS_E_WORKSPACE (-4)
+
+#define COGS_DT_BF16 0
+#define COGS_DT_F32 1
+
+static inline int cogs_hip_check(hipError_t e) { return e == hipSuccess ? COGS_OK : COGS_E_HIP; }
+#define COGS_LAUNCH_CHECK() cogs_hip_check(hipGetLastError())

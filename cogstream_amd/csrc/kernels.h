@@ -1,0 +1,98 @@
+// Internal launcher interface between the C-ABI layer (capi.hip) and the kernel files.
+// Every launcher enqueues on the given stream, never synchronises, never allocates, and
+// returns a COGS_* status (0 = ok).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define COGS_ACT_NONE 0
+#define COGS_ACT_GELU_TANH 1
+#define COGS_ACT_GELU_ERF 2
+#define COGS_ACT_SWIGLU 3
+
+struct CogsGemm {
+    int dtype = 0;                 // COGS_DT_*
+    const void* A = nullptr; long lda = 0;   // [M,K], elements per row
+    const void* W = nullptr; long ldw = 0;   // [N,K]
+    void* C = nullptr; long ldc = 0;         // [M,N] (SWIGLU: [M,N/2])
+    const void* bias = nullptr;              // [N]
+    const void* residual = nullptr; long ldr = 0;
+    int M = 0, N = 0, K = 0;
+    int act = 0;
+    int out_f32 = 0;
+    const float* rope_cos = nullptr;         // [M, head_dim/2]
+    const float* rope_sin = nullptr;
+    int rope_cols = 0;
+    int head_dim = 0;
+};
+int cogs_k_gemm(hipStream_t st, const CogsGemm& g);
+
+struct CogsAttn {
+    int dtype = 0;
+    const void* Q = nullptr; const void* K = nullptr; const void* V = nullptr; void* O = nullptr;
+    long ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+    const int* cu_seqlens = nullptr;  // device [nseg+1]; block-diagonal segments (q and k alike)
+    int nseg = 1;
+    int max_seqlen = 0;
+    const int* row_lo = nullptr;      // device [q_len]: same-segment key range, enables the
+    const int* row_hi = nullptr;      //   "global attention + bias" mode of the eager reference
+    float bias = 0.f;
+    int q_len = 0, kv_len = 0;
+    int hq = 1, hkv = 1, head_dim = 0;
+    float scale = 1.f;
+    int causal = 0;
+    int q_pos0 = 0;
+    int force_rowwise = 0;
+    int nsplit = 1;                   // >1: split the keys over blocks (decode); needs ws
+    void* ws = nullptr;               // nsplit*q_len*hq*(head_dim+2) floats
+    size_t ws_bytes = 0;
+};
+int cogs_k_attention(hipStream_t st, const CogsAttn& a);
+
+
+// norms
+int cogs_k_layernorm(hipStream_t st, int dtype, const void* x, void* y, const void* gamma, const void* beta,
+                     int rows, int H, float eps);
+int cogs_k_rmsnorm(hipStream_t st, int dtype, const void* x, void* y, const void* gamma, int rows, int H, float eps);
+// y[r] = mean_{i<group} LN(x[group*r+i])   (post_layernorm + 2x2 bilinear merge)
+int cogs_k_ln_merge(hipStream_t st, int dtype, const void* x, void* y, const void* gamma, const void* beta,
+                    int out_rows, int group, int H, float eps);
+
+// vision front-end helpers
+int cogs_k_pack_rows(hipStream_t st, int in_dtype, int out_dtype, const void* in, long ld_in, void* out,
+                     long ld_out, int rows, int cols_in, int cols_out);
+int cogs_k_vit_rope_table(hipStream_t st, float* cos_t, float* sin_t, int row0, int t, int gh, int gw, int ms,
+                          const float* inv_freq, int n_freq);
+int cogs_k_llm_rope_table(hipStream_t st, float* cos_t, float* sin_t, const int* pos, int pos0, int rows,
+                          const float* inv_freq, int n_freq);
+
+// token compression
+int cogs_k_pixdiff_mask(hipStream_t st, int dtype, const void* pix, int t, int tokens_per_frame, int row_elems,
+                        float thr, int min_tokens, uint8_t* mask);
+int cogs_k_mask_fix(hipStream_t st, uint8_t* mask, int t, int tokens_per_frame, int min_tokens, const uint8_t* minor);
+int cogs_k_frame_mean_to_slot0(hipStream_t st, int dtype, void* feats, int P, int D, const int* frames, int n_frames);
+int cogs_k_gather_rows(hipStream_t st, int dtype, const void* table_a, const void* table_b, const int64_t* idx,
+                       void* out, int rows, int D);
+int cogs_k_mean_rows(hipStream_t st, int dtype, const void* x, long ldx, int rows, int D, float* out);
+int cogs_k_cosine(hipStream_t st, const float* a, const float* b, int n, int D, float* out);
+
+// time-aware k-means
+int cogs_k_kmeans_sqdist(hipStream_t st, int dtype, const void* feats, int T, long PD, const float* centres,
+                         const int* centre_rows, int K, float* partial, int nslices, float* dist2);
+size_t cogs_k_kmeans_ws(int T, long PD, int K, int* nslices);
+int cogs_k_kmeans_assign(hipStream_t st, const float* dist2, const float* ts, const float* centre_ts, int T, int K,
+                         float alpha, int64_t* assign, int* counts);
+int cogs_k_kmeans_update(hipStream_t st, int dtype, const void* feats, const float* ts, int T, long PD, int K,
+                         const int64_t* assign, const int* reseed_rows, float* centres, float* centre_ts,
+                         float* shift_partial, int nblk, float* shift_out);
+int cogs_k_kmeans_update_blocks(long PD);
+
+// LLM helpers
+int cogs_k_copy_cols(hipStream_t st, int dtype, const void* src, long ld_src, void* dst, long ld_dst, int rows, int cols);
+int cogs_k_argmax(hipStream_t st, const float* logits, int n, int64_t* out, float* ws);
+// HF logits processors on one fp32 row: repetition penalty over `prev` (gather-then-scatter, so
+// duplicates are penalised once), allowed-id mask (others -> -inf), temperature; `tmp` >= n_prev floats
+int cogs_k_logits_process(hipStream_t st, float* logits, int n, const int64_t* prev, int n_prev, float rep_penalty,
+                          const int32_t* allowed, int n_allowed, float temperature, float* tmp);
+// the top_k largest logits in descending order (ties: lower index first); ws >= 2*n floats
+int cogs_k_topk(hipStream_t st, const float* logits, int n, int top_k, float* topk_val, int32_t* topk_idx, float* ws);

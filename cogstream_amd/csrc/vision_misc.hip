@@ -1,0 +1,112 @@
+// Small HBM-bound helpers around the ViT encoder: patch-row packing and rotary tables.
+//
+//   pack_rows     pixel_values [N,588] (fp32 or bf16) -> compute dtype, K padded to a multiple of
+//                 the GEMM slab (640) so that patch-embed (nn.Conv2d k=s=14,
+//                 model/modeling_videollama3_encoder.py:194-210) is a plain row-major GEMM.
+//   vit_rope_table cos/sin of the 2-D rotary angles in merge-window row order
+//                 (rot_pos_emb, model/modeling_videollama3_encoder.py:405-434; VisionRotaryEmbedding
+//                 :173-183): row r of a frame -> window r/ms^2, (dy,dx) inside it; angles are
+//                 [h*inv_freq[0..n), w*inv_freq[0..n)].
+//   llm_rope_table cos/sin(pos * inv_freq) for Qwen2 (theta 1e6, rotate_half pairs d, d+hd/2).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const TI* __restrict__ in, long ld_in, TO* __restrict__ out,
+                                                        long ld_out, int rows, int cols_in, int cols_out) {
+    const int cpr = cols_out >> 2;  // 4-element groups per output row
+    const long total = (long)rows * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cpr;
+        const int c = (int)(i % cpr) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < cols_in) {
+            v = ld4_f<TI>(in + r * ld_in + c);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < cols_in) v[e] = ld_f<TI>(in + r * ld_in + c + e);
+        }
+        st4_f<TO>(out + r * ld_out + c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void vit_rope_kernel(float* cos_t, float* sin_t, int row0, int t, int gh, int gw,
+                                                       int ms, const float* inv_freq, int nf) {
+    const int per_frame = gh * gw;
+    const long total = (long)t * per_frame * 2 * nf;
+    const int wpr = gw / ms;  // merge windows per row
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % (2 * nf));
+        const long row = i / (2 * nf);
+        const int r = (int)(row % per_frame);
+        const int win = r / (ms * ms), in = r % (ms * ms);
+        const int hpos = (win / wpr) * ms + in / ms;
+        const int wpos = (win % wpr) * ms + in % ms;
+        const float ang = (f < nf) ? (float)hpos * inv_freq[f] : (float)wpos * inv_freq[f - nf];
+        const long o = ((long)row0 + row) * (2 * nf) + f;
+        cos_t[o] = cosf(ang);
+        sin_t[o] = sinf(ang);
+    }
+}
+
+__global__ __launch_bounds__(256) void llm_rope_kernel(float* cos_t, float* sin_t, const int* pos, int pos0, int rows,
+                                                       const float* inv_freq, int nf) {
+    const long total = (long)rows * nf;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % nf);
+        const int r = (int)(i / nf);
+        const int pp = pos ? pos[r] : pos0 + r;
+        const float ang = (float)pp * inv_freq[f];
+        cos_t[i] = cosf(ang);
+        sin_t[i] = sinf(ang);
+    }
+}
+
+inline int grid_for(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+int cogs_k_pack_rows(hipStream_t st, int in_dtype, int out_dtype, const void* in, long ld_in, void* out, long ld_out,
+                     int rows, int cols_in, int cols_out) {
+    if (rows <= 0) return COGS_OK;
+    if (cols_out % 4 || cols_in > cols_out || ld_in % 4 || ld_out % 4) return COGS_E_INVALID;
+    const int g = grid_for((long)rows * (cols_out / 4));
+    if (in_dtype == COGS_DT_F32 && out_dtype == COGS_DT_BF16)
+        hipLaunchKernelGGL((pack_rows_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)in, ld_in,
+                           (bf16_t*)out, ld_out, rows, cols_in, cols_out);
+    else if (in_dtype == COGS_DT_BF16 && out_dtype == COGS_DT_BF16)
+        hipLaunchKernelGGL((pack_rows_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)in, ld_in,
+                           (bf16_t*)out, ld_out, rows, cols_in, cols_out);
+    else if (in_dtype == COGS_DT_F32 && out_dtype == COGS_DT_F32)
+        hipLaunchKernelGGL((pack_rows_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)in, ld_in,
+                           (float*)out, ld_out, rows, cols_in, cols_out);
+    else if (in_dtype == COGS_DT_BF16 && out_dtype == COGS_DT_F32)
+        hipLaunchKernelGGL((pack_rows_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)in, ld_in,
+                           (float*)out, ld_out, rows, cols_in, cols_out);
+    else
+        return COGS_E_INVALID;
+    return COGS_LAUNCH_CHECK();
+}
+
+int cogs_k_vit_rope_table(hipStream_t st, float* cos_t, float* sin_t, int row0, int t, int gh, int gw, int ms,
+                          const float* inv_freq, int n_freq) {
+    if (t <= 0 || gh <= 0 || gw <= 0 || ms <= 0 || gh % ms || gw % ms) return COGS_E_INVALID;
+    const long total = (long)t * gh * gw * 2 * n_freq;
+    hipLaunchKernelGGL(vit_rope_kernel, dim3(grid_for(total)), dim3(256), 0, st, cos_t, sin_t, row0, t, gh, gw, ms,
+                       inv_freq, n_freq);
+    return COGS_LAUNCH_CHECK();
+}
+
+int cogs_k_llm_rope_table(hipStream_t st, float* cos_t, float* sin_t, const int* pos, int pos0, int rows,
+                          const float* inv_freq, int n_freq) {
+    if (rows <= 0) return COGS_OK;
+    hipLaunchKernelGGL(llm_rope_kernel, dim3(grid_for((long)rows * n_freq)), dim3(256), 0, st, cos_t, sin_t, pos, pos0,
+                       rows, inv_freq, n_freq);
+    return COGS_LAUNCH_CHECK();
+}

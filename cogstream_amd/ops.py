@@ -1,0 +1,229 @@
+"""Operator-level wrappers: torch CUDA tensors in, HIP kernels through the C ABI, torch tensors out.
+torch is used for device memory and streams only; no arithmetic happens here."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import check, current_stream, dtype_code, ptr
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.CogsError("cogstream_amd ops need CUDA (ROCm) tensors; there is no CPU path")
+
+
+def pad_cols(x: torch.Tensor, mult: int) -> torch.Tensor:
+    """zero-pad the last dim of a 2-D tensor to a multiple of `mult` (host-side weight packing helper)"""
+    k = x.shape[-1]
+    kp = (k + mult - 1) // mult * mult
+    if kp == k:
+        return x.contiguous()
+    out = x.new_zeros(*x.shape[:-1], kp)
+    out[..., :k] = x
+    return out
+
+
+def k_slab(dtype) -> int:
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
+         residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False,
+         rope_cos: Optional[torch.Tensor] = None, rope_sin: Optional[torch.Tensor] = None, rope_cols: int = 0,
+         head_dim: int = 0) -> torch.Tensor:
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)  (see cogs_gemm in include/cogs.h)"""
+    _need_cuda(a, w, bias, residual, out)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    ncols = N // 2 if act == L.ACT_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, ncols, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    d = L.GemmDesc()
+    d.dtype = dtype_code(a.dtype)
+    d.A, d.lda = ptr(a), a.stride(0)
+    d.W, d.ldw = ptr(w), w.stride(0)
+    d.C, d.ldc = ptr(out), out.stride(0)
+    d.bias = ptr(bias)
+    d.residual, d.ldr = ptr(residual), (residual.stride(0) if residual is not None else 0)
+    d.M, d.N, d.K = M, N, K
+    d.act, d.out_f32 = act, int(out_f32)
+    d.rope_cos, d.rope_sin, d.rope_cols, d.head_dim = ptr(rope_cos), ptr(rope_sin), rope_cols, head_dim
+    check(L.lib.cogs_gemm(current_stream(), C.byref(d)), "cogs_gemm")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hq: int, hkv: int, head_dim: int,
+              scale: Optional[float] = None, cu_seqlens: Optional[torch.Tensor] = None, max_seqlen: int = 0,
+              row_lo: Optional[torch.Tensor] = None, row_hi: Optional[torch.Tensor] = None, bias: float = 0.0,
+              causal: bool = False, q_pos0: int = 0, force_rowwise: bool = False, nsplit: int = 1,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """token-major attention: q [Lq, hq*hd] (may be a column view of a fused buffer), k/v [Lk, hkv*hd]"""
+    _need_cuda(q, k, v)
+    Lq, Lk = q.shape[0], k.shape[0]
+    if out is None:
+        out = torch.empty(Lq, hq * head_dim, device=q.device, dtype=q.dtype)
+    d = L.AttnDesc()
+    d.dtype = dtype_code(q.dtype)
+    d.Q, d.K, d.V, d.O = ptr(q), ptr(k), ptr(v), ptr(out)
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    d.cu_seqlens = ptr(cu_seqlens)
+    d.nseg = (cu_seqlens.numel() - 1) if cu_seqlens is not None else 1
+    d.max_seqlen = max_seqlen
+    d.row_lo, d.row_hi, d.bias = ptr(row_lo), ptr(row_hi), bias
+    d.q_len, d.kv_len = Lq, Lk
+    d.hq, d.hkv, d.head_dim = hq, hkv, head_dim
+    d.scale = scale if scale is not None else 1.0 / math.sqrt(head_dim)
+    d.causal, d.q_pos0 = int(causal), q_pos0
+    d.force_rowwise = int(force_rowwise)
+    ws = None
+    if nsplit > 1:
+        ws = torch.empty(nsplit * Lq * hq * (head_dim + 2), device=q.device, dtype=torch.float32)
+        d.nsplit, d.ws, d.ws_bytes = nsplit, ptr(ws), ws.numel() * 4
+    else:
+        d.nsplit = 1
+    check(L.lib.cogs_attention(current_stream(), C.byref(d)), "cogs_attention")
+    return out
+
+
+def layernorm(x, gamma, beta, eps: float = 1e-6):
+    _need_cuda(x, gamma, beta)
+    y = torch.empty_like(x)
+    check(L.lib.cogs_layernorm(current_stream(), dtype_code(x.dtype), ptr(x), ptr(y), ptr(gamma), ptr(beta),
+                               x.shape[0], x.shape[1], eps), "cogs_layernorm")
+    return y
+
+
+def rmsnorm(x, gamma, eps: float = 1e-6):
+    _need_cuda(x, gamma)
+    y = torch.empty_like(x)
+    check(L.lib.cogs_rmsnorm(current_stream(), dtype_code(x.dtype), ptr(x), ptr(y), ptr(gamma), x.shape[0],
+                             x.shape[1], eps), "cogs_rmsnorm")
+    return y
+
+
+def ln_merge(x, gamma, beta, group: int, eps: float = 1e-6):
+    _need_cuda(x, gamma, beta)
+    y = torch.empty(x.shape[0] // group, x.shape[1], device=x.device, dtype=x.dtype)
+    check(L.lib.cogs_ln_merge(current_stream(), dtype_code(x.dtype), ptr(x), ptr(y), ptr(gamma), ptr(beta),
+                              y.shape[0], group, x.shape[1], eps), "cogs_ln_merge")
+    return y
+
+
+def pixdiff_mask(pix: torch.Tensor, t: int, P: int, thr: float = 0.1, min_tokens: int = 1,
+                 minor: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pix: one video's rows [t*P*merge^2, 588] -> uint8 keep-mask [t*P]"""
+    _need_cuda(pix, minor)
+    assert pix.is_contiguous()
+    E = pix.numel() // (t * P)
+    mask = torch.empty(t * P, device=pix.device, dtype=torch.uint8)
+    check(L.lib.cogs_pixdiff_mask(current_stream(), dtype_code(pix.dtype), ptr(pix), t, P, E, thr, min_tokens,
+                                  ptr(minor), ptr(mask)), "cogs_pixdiff_mask")
+    return mask
+
+
+def frame_mean_to_slot0(feats: torch.Tensor, P: int, frames: torch.Tensor) -> None:
+    _need_cuda(feats, frames)
+    assert feats.is_contiguous() and frames.dtype == torch.int32
+    check(L.lib.cogs_frame_mean_to_slot0(current_stream(), dtype_code(feats.dtype), ptr(feats), P, feats.shape[1],
+                                         ptr(frames), frames.numel()), "cogs_frame_mean_to_slot0")
+
+
+def gather_rows(table_a: torch.Tensor, table_b: Optional[torch.Tensor], idx: torch.Tensor) -> torch.Tensor:
+    _need_cuda(table_a, table_b, idx)
+    assert idx.dtype == torch.int64 and table_a.is_contiguous()
+    out = torch.empty(idx.numel(), table_a.shape[1], device=table_a.device, dtype=table_a.dtype)
+    check(L.lib.cogs_gather_rows(current_stream(), dtype_code(table_a.dtype), ptr(table_a), ptr(table_b), ptr(idx),
+                                 ptr(out), idx.numel(), table_a.shape[1]), "cogs_gather_rows")
+    return out
+
+
+def mean_rows(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+    check(L.lib.cogs_mean_rows(current_stream(), dtype_code(x.dtype), ptr(x), x.stride(0), x.shape[0], x.shape[1],
+                               ptr(out)), "cogs_mean_rows")
+    return out
+
+
+def cosine(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _need_cuda(a, b)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and b.is_contiguous()
+    out = torch.empty(b.shape[0], device=a.device, dtype=torch.float32)
+    check(L.lib.cogs_cosine(current_stream(), ptr(a), ptr(b), b.shape[0], b.shape[1], ptr(out)), "cogs_cosine")
+    return out
+
+
+def pack_rows(x: torch.Tensor, out_dtype, cols_out: int) -> torch.Tensor:
+    _need_cuda(x)
+    out = torch.empty(x.shape[0], cols_out, device=x.device, dtype=out_dtype)
+    check(L.lib.cogs_pack_rows(current_stream(), dtype_code(x.dtype), dtype_code(out_dtype), ptr(x), x.stride(0),
+                               ptr(out), cols_out, x.shape[0], x.shape[1], cols_out), "cogs_pack_rows")
+    return out
+
+
+def kmeans_workspace(T: int, PD: int, K: int, device) -> torch.Tensor:
+    n = C.c_size_t()
+    check(L.lib.cogs_kmeans_workspace_bytes(T, PD, K, C.byref(n)), "cogs_kmeans_workspace_bytes")
+    return torch.empty(n.value, device=device, dtype=torch.uint8)
+
+
+def kmeans_sqdist(feats, centres, centre_rows, K: int, ws) -> torch.Tensor:
+    T, PD = feats.shape
+    dist2 = torch.empty(T, K, device=feats.device, dtype=torch.float32)
+    check(L.lib.cogs_kmeans_sqdist(current_stream(), dtype_code(feats.dtype), ptr(feats), T, PD, ptr(centres),
+                                   ptr(centre_rows), K, ptr(dist2), ptr(ws), ws.numel()), "cogs_kmeans_sqdist")
+    return dist2
+
+
+def kmeans_assign(dist2, ts, centre_ts, alpha: float):
+    T, K = dist2.shape
+    assign = torch.empty(T, device=dist2.device, dtype=torch.int64)
+    counts = torch.empty(K, device=dist2.device, dtype=torch.int32)
+    check(L.lib.cogs_kmeans_assign(current_stream(), ptr(dist2), ptr(ts), ptr(centre_ts), T, K, alpha, ptr(assign),
+                                   ptr(counts)), "cogs_kmeans_assign")
+    return assign, counts
+
+
+def kmeans_update(feats, ts, assign, reseed_rows, centres, centre_ts, ws) -> torch.Tensor:
+    T, PD = feats.shape
+    K = centres.shape[0]
+    shift = torch.empty(1, device=feats.device, dtype=torch.float32)
+    check(L.lib.cogs_kmeans_update(current_stream(), dtype_code(feats.dtype), ptr(feats), ptr(ts), T, PD, K,
+                                   ptr(assign), ptr(reseed_rows), ptr(centres), ptr(centre_ts), ptr(shift), ptr(ws),
+                                   ws.numel()), "cogs_kmeans_update")
+    return shift
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    _need_cuda(logits)
+    out = torch.empty(1, device=logits.device, dtype=torch.int64)
+    ws = torch.empty(128, device=logits.device, dtype=torch.float32)
+    check(L.lib.cogs_argmax(current_stream(), ptr(logits), logits.numel(), ptr(out), ptr(ws)), "cogs_argmax")
+    return out
+
+
+def logits_process(logits: torch.Tensor, prev: Optional[torch.Tensor], repetition_penalty: float = 1.0,
+                   allowed: Optional[torch.Tensor] = None, temperature: float = 1.0) -> None:
+    """in place on a fp32 [vocab] row"""
+    _need_cuda(logits, prev, allowed)
+    n_prev = prev.numel() if prev is not None else 0
+    tmp = torch.empty(max(n_prev, 1), device=logits.device, dtype=torch.float32)
+    check(L.lib.cogs_logits_process(current_stream(), ptr(logits), logits.numel(), ptr(prev), n_prev,
+                                    repetition_penalty, ptr(allowed), allowed.numel() if allowed is not None else 0,
+                                    temperature, ptr(tmp)), "cogs_logits_process")
+
+
+def topk(logits: torch.Tensor, k: int):
+    _need_cuda(logits)
+    val = torch.empty(k, device=logits.device, dtype=torch.float32)
+    idx = torch.empty(k, device=logits.device, dtype=torch.int32)
+    ws = torch.empty(logits.numel(), device=logits.device, dtype=torch.float32)
+    check(L.lib.cogs_topk(current_stream(), ptr(logits), logits.numel(), k, ptr(val), ptr(idx), ptr(ws)), "cogs_topk")
+    return val, idx

@@ -1,0 +1,237 @@
+/*
+ * cogs.h -- C ABI of libcogs_hip.so: the MI355X (gfx950) hot path of the CogReasoner
+ * streaming-VQA inference pipeline (reference: LiamZhao326/CogStream, model/ package).
+ *
+ * The reference has no native ABI: its hot path is Python calling torch / transformers /
+ * flash-attn. This header is the boundary a maintainer binds with
+ * ctypes from the three reference seams
+ *     vision_encoder(pixel_values, grid_sizes, merge_sizes)   model/cogreasoner_chat.py:270-274
+ *     kmeans_with_time_min_max(features, timestamps, K)        model/cogreasoner_chat.py:283
+ *     get_model()(inputs_embeds=..) / super().generate(..)     model/cogreasoner_chat.py:312-316,802
+ * (the stub is shown in INTEGRATION.md; cogstream_amd/_lib.py is the binding this repo uses).
+ *
+ * Rules that hold for every entry point:
+ *   - extern "C", plain pointers and sizes; returns a cogs_status (0 = ok, negative = error);
+ *     never throws, never synchronises the device unless stated, never allocates
+ *     caller-visible memory (workspace sizes are queried, then passed in);
+ *   - all tensor pointers are DEVICE pointers owned by the caller (e.g. torch tensors'
+ *     data_ptr()); small shape arrays marked "host" are host pointers read during the call;
+ *   - `stream` is a hipStream_t; work is enqueued on it in call order;
+ *   - `dtype` is the storage + arithmetic input type of activations/weights:
+ *     COGS_DT_BF16 (production; fp32 accumulation) or COGS_DT_F32 (parity mode, exact-f32 MFMA);
+ *   - a handle is bound to one device; calls on one handle are not thread-safe.
+ */
+#ifndef COGS_H_
+#define COGS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int cogs_status;
+#define COGS_OK 0
+#define COGS_E_INVALID (-1)     /* bad argument / unsupported shape alignment */
+#define COGS_E_HIP (-2)         /* a HIP runtime call or kernel launch failed */
+#define COGS_E_UNSUPPORTED (-3)
+#define COGS_E_WORKSPACE (-4)   /* workspace missing or too small */
+
+#define COGS_DT_BF16 0
+#define COGS_DT_F32 1
+
+#define COGS_ACT_NONE 0
+#define COGS_ACT_GELU_TANH 1    /* ACT2FN["gelu_pytorch_tanh"], ViT fc1 */
+#define COGS_ACT_GELU_ERF 2     /* nn.GELU(), projector */
+#define COGS_ACT_SWIGLU 3       /* silu(gate)*up on (gate_i, up_i)-interleaved weight rows */
+
+/* ViT attention semantics (SURVEY.md headline fact 2) */
+#define COGS_ATTN_BLOCK_DIAG 0        /* per-frame attention = flash_attn_varlen path (:309-312) */
+#define COGS_ATTN_REF_EAGER_GLOBAL 1  /* eager path: global attention, +1.0 logit on same-frame pairs (:257-266) */
+
+typedef struct cogs_ctx* cogs_handle;
+typedef void* cogs_stream; /* hipStream_t */
+
+const char* cogs_status_string(cogs_status s);
+const char* cogs_version(void);
+
+cogs_status cogs_create(int device, cogs_handle* out);
+cogs_status cogs_destroy(cogs_handle h);
+
+/* ------------------------------------------------------------------ operator level ---- */
+
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T). nn.Linear / Conv2d(k=s=14) replacement
+ * (model/modeling_videollama3_encoder.py:194-210,246-248,275,369-373; cogreasoner_chat.py:179-211).
+ * K must be a multiple of 64 (bf16) / 32 (f32) -- pad with zeros; N a multiple of 4;
+ * lda/ldw/ldc/ldr in elements, rows 16-byte aligned. bias [N] and residual [M,N] nullable.
+ * rope: if rope_cos != NULL, columns [0, rope_cols) are rotated with tables [M, head_dim/2] (fp32);
+ * weight rows must be packed so that columns (2i, 2i+1) of a head are the rotate_half pair
+ * (i, i + head_dim/2). act = COGS_ACT_*; SWIGLU writes [M, N/2]. out_f32: store fp32. */
+typedef struct {
+    int dtype;
+    const void* A; int64_t lda;
+    const void* W; int64_t ldw;
+    void* C; int64_t ldc;
+    const void* bias;
+    const void* residual; int64_t ldr;
+    int M, N, K;
+    int act;
+    int out_f32;
+    const float* rope_cos;
+    const float* rope_sin;
+    int rope_cols;
+    int head_dim;
+} cogs_gemm_desc;
+cogs_status cogs_gemm(cogs_stream stream, const cogs_gemm_desc* d);
+
+/* Attention over token-major Q/K/V (row stride ld*, head h at column h*head_dim).
+ * cu_seqlens (device int32 [nseg+1], nullable): block-diagonal segments as in
+ * flash_attn_varlen_func (modeling_videollama3_encoder.py:309-312, cu_seqlens :439-440).
+ * row_lo/row_hi (device int32 [q_len], nullable): eager-reference mode, every query sees all
+ * keys and `bias` is added to the logits of keys in [row_lo[q], row_hi[q]) (:257-266).
+ * causal: key j visible to query i iff j <= i + q_pos0 (Qwen2; q_pos0 = kv_len - q_len).
+ * nsplit > 1 splits the keys over workgroups (decode); ws >= nsplit*q_len*hq*(head_dim+2)*4 bytes. */
+typedef struct {
+    int dtype;
+    const void* Q; const void* K; const void* V; void* O;
+    int64_t ldq, ldk, ldv, ldo;
+    const int32_t* cu_seqlens; int nseg; int max_seqlen;
+    const int32_t* row_lo; const int32_t* row_hi; float bias;
+    int q_len, kv_len;
+    int hq, hkv, head_dim;
+    float scale;
+    int causal; int q_pos0;
+    int force_rowwise;      /* use the generic fp32-math kernel (any head_dim <= 256) */
+    int nsplit; void* ws; size_t ws_bytes;
+} cogs_attn_desc;
+cogs_status cogs_attention(cogs_stream stream, const cogs_attn_desc* d);
+
+/* nn.LayerNorm (modeling_videollama3_encoder.py:382-384,475) / Qwen2RMSNorm; H % 8 == 0 */
+cogs_status cogs_layernorm(cogs_stream stream, int dtype, const void* x, void* y, const void* gamma,
+                           const void* beta, int rows, int H, float eps);
+cogs_status cogs_rmsnorm(cogs_stream stream, int dtype, const void* x, void* y, const void* gamma, int rows,
+                         int H, float eps);
+/* y[r] = mean_{i<group} LayerNorm(x[group*r+i]): post_layernorm + 2x2 bilinear merge (:482-501) */
+cogs_status cogs_ln_merge(cogs_stream stream, int dtype, const void* x, void* y, const void* gamma,
+                          const void* beta, int out_rows, int group, int H, float eps);
+
+/* Pixel-difference keep-mask of merged visual tokens (model/cogreasoner_chat.py:405-422).
+ * pix: one video's pixel_values viewed as [t, P, E] (E = merge^2 * 588); mask: uint8 [t*P].
+ * minor (device uint8 [t], nullable): frames reduced to their token 0. */
+cogs_status cogs_pixdiff_mask(cogs_stream stream, int dtype, const void* pix, int t, int P, int E, float thr,
+                              int min_tokens, const uint8_t* minor, uint8_t* mask);
+/* token 0 of each listed frame <- mean over the frame's P tokens, in place (cogreasoner_chat.py:434-447) */
+cogs_status cogs_frame_mean_to_slot0(cogs_stream stream, int dtype, void* feats, int P, int D,
+                                     const int32_t* frames, int n_frames);
+/* out[r] = idx[r] >= 0 ? table_a[idx[r]] : table_b[-idx[r]-1]   (embed_tokens + masked scatter, :567-572) */
+cogs_status cogs_gather_rows(cogs_stream stream, int dtype, const void* table_a, const void* table_b,
+                             const int64_t* idx, void* out, int rows, int D);
+/* out[D] (fp32) = mean over rows (torch.mean(last_hidden_state, dim=1), :317,323) */
+cogs_status cogs_mean_rows(cogs_stream stream, int dtype, const void* x, int64_t ldx, int rows, int D, float* out);
+/* out[i] = cos(a, b[i])  (F.cosine_similarity, :325) */
+cogs_status cogs_cosine(cogs_stream stream, const float* a, const float* b, int n, int D, float* out);
+
+/* Time-aware k-means steps (model/kmeans_with_time.py:4-137); the host keeps the RNG draws.
+ * feats [T, PD] (dtype), centres fp32 [K, PD], ts/centre_ts fp32. K <= 32, T <= 1024. */
+cogs_status cogs_kmeans_workspace_bytes(int T, int64_t PD, int K, size_t* bytes);
+/* dist2[T,K] = squared L2 distance to the centres; centre_rows (device int32 [K], nullable)
+ * selects feature rows as centres instead of `centres` (k-means++ init, :46-50) */
+cogs_status cogs_kmeans_sqdist(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD,
+                               const float* centres, const int32_t* centre_rows, int K, float* dist2,
+                               void* ws, size_t ws_bytes);
+/* per-row min-max normalised feature + time distance, argmin (:76-104); counts int32 [K] */
+cogs_status cogs_kmeans_assign(cogs_stream stream, const float* dist2, const float* ts, const float* centre_ts,
+                               int T, int K, float alpha, int64_t* assign, int32_t* counts);
+/* centres/centre_ts <- cluster means, empty cluster k <- row reseed_rows[k] (:107-120);
+ * shift_out[0] = sum_k ||dc_k||_2 + ||d centre_ts||_2 (:123-125) */
+cogs_status cogs_kmeans_update(cogs_stream stream, int dtype, const void* feats, const float* ts, int T,
+                               int64_t PD, int K, const int64_t* assign, const int32_t* reseed_rows,
+                               float* centres, float* centre_ts, float* shift_out, void* ws, size_t ws_bytes);
+/* dtype conversion / zero-padded row copy (features.to(float32), patch padding) */
+cogs_status cogs_pack_rows(cogs_stream stream, int in_dtype, int out_dtype, const void* in, int64_t ld_in,
+                           void* out, int64_t ld_out, int rows, int cols_in, int cols_out);
+
+/* logits post-processing (model/generation_config.json:2-12; qaselect_module_predict.py:86-103) */
+cogs_status cogs_argmax(cogs_stream stream, const float* logits, int n, int64_t* out, void* ws /* >= 512 B */);
+cogs_status cogs_logits_process(cogs_stream stream, float* logits, int n, const int64_t* prev, int n_prev,
+                                float repetition_penalty, const int32_t* allowed, int n_allowed,
+                                float temperature, float* tmp /* >= n_prev floats */);
+cogs_status cogs_topk(cogs_stream stream, const float* logits, int n, int top_k, float* topk_val,
+                      int32_t* topk_idx, float* ws /* >= n floats */);
+
+/* ------------------------------------------------------------------ vision encoder ---- */
+
+/* Packed ViT weights (borrowed device pointers, `dtype` elements). HF names (A18):
+ * model.vision_encoder.{embeddings.patch_embedding, encoder.layers.N.*, post_layernorm}.
+ * Packing done once at load (cogstream_amd/weights.py): patch_w [hidden, patch_pad] zero padded;
+ * qkv_w [3*hidden, hidden] = q,k,v rows stacked, q/k rows of each head interleaved as rotary pairs;
+ * fc1_w [inter_pad, hidden], fc1_b [inter_pad], fc2_w [hidden, inter_pad] zero padded. */
+typedef struct {
+    const void *ln1_g, *ln1_b, *qkv_w, *qkv_b, *o_w, *o_b, *ln2_g, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} cogs_vit_layer;
+typedef struct {
+    int dtype;
+    int hidden, inter_pad, layers, heads, patch_dim, patch_pad;
+    float ln_eps;
+    const void *patch_w, *patch_b, *post_ln_g, *post_ln_b;
+    const cogs_vit_layer* layer; /* host array [layers], copied by cogs_vit_load */
+} cogs_vit_weights;
+cogs_status cogs_vit_load(cogs_handle h, const cogs_vit_weights* w);
+cogs_status cogs_vit_workspace_bytes(cogs_handle h, int64_t n_patches, size_t* bytes);
+/* Videollama3VisionEncoderModel.forward (modeling_videollama3_encoder.py:479-510).
+ * pixel_values [N,588] (pix_dtype fp32 or bf16), grid_sizes host int64 [V,3] = (t,gh,gw),
+ * merge_sizes host int64 [V]; out_tokens [M, hidden] in the weights' dtype. */
+cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
+                            const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
+                            void* out_tokens, void* ws, size_t ws_bytes);
+
+/* MlpGeluProjector (model/cogreasoner_chat.py:199-211): Linear -> GELU(erf) -> Linear */
+typedef struct {
+    int dtype; int in_dim, out_dim;
+    const void *w1, *b1, *w2, *b2;
+} cogs_proj_weights;
+cogs_status cogs_proj_load(cogs_handle h, const cogs_proj_weights* w);
+cogs_status cogs_project(cogs_handle h, cogs_stream stream, const void* tokens, int M, void* out, void* ws,
+                         size_t ws_bytes /* >= M*out_dim elements */);
+
+/* ------------------------------------------------------------------------- Qwen2 ------ */
+
+/* Packed Qwen2 weights. HF names: model.layers.N.{input_layernorm, self_attn.{q,k,v,o}_proj,
+ * post_attention_layernorm, mlp.{gate,up,down}_proj}, model.norm, lm_head (untied).
+ * qkv_w [(hq+2*hkv)*hd, hidden] with q/k head rows interleaved as rotary pairs, qkv_b likewise;
+ * gu_w [2*inter, hidden] rows interleaved (gate_i, up_i); down_w [hidden, inter];
+ * lm_head [vocab, hidden] (vocab % 4 == 0). */
+typedef struct {
+    const void *in_ln, *qkv_w, *qkv_b, *o_w, *post_ln, *gu_w, *down_w;
+} cogs_llm_layer;
+typedef struct {
+    int dtype;
+    int hidden, inter, layers, heads, kv_heads, head_dim, vocab;
+    float rms_eps, rope_theta;
+    const void *final_norm, *lm_head;
+    const cogs_llm_layer* layer; /* host array [layers] */
+} cogs_llm_weights;
+cogs_status cogs_llm_load(cogs_handle h, const cogs_llm_weights* w);
+
+/* KV cache, caller-owned: k and v are [layers][max_len][kv_heads*head_dim] in the weights' dtype */
+typedef struct {
+    void* k; void* v;
+    int max_len;
+    int len;      /* tokens already cached; advanced by cogs_llm_forward */
+} cogs_kv;
+cogs_status cogs_llm_workspace_bytes(cogs_handle h, int max_tokens, int max_context, size_t* bytes);
+/* One Qwen2Model forward over S new tokens given as embeddings [S, hidden] at positions
+ * kv->len .. kv->len+S-1 (causal over cache + new tokens); kv == NULL: stateless forward
+ * (event summaries, cogreasoner_chat.py:303-316). Outputs, each nullable:
+ *   last_logits  fp32 [vocab]   lm_head(norm(h_last))          (generate / decode)
+ *   pooled_mean  fp32 [hidden]  mean_t norm(h_t)                (cogreasoner_chat.py:317,323)
+ *   hidden_out   [S, hidden]    norm(h)  (last_hidden_state) */
+cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embeds, int S, cogs_kv* kv,
+                             float* last_logits, float* pooled_mean, void* hidden_out, void* ws,
+                             size_t ws_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COGS_H_ */

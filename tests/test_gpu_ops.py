@@ -1,0 +1,335 @@
+"""Operator-level parity: every HIP kernel, called through the C ABI, against a plain torch fp32
+restatement of the same op on the same seeded inputs. Tolerances are stated per test:
+bf16 storage => ~2^-8 relative per rounding; fp32 parity mode => 1e-4 or tighter."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from cogstream_amd import ops
+    return ops
+
+
+def _L():
+    from cogstream_amd import _lib
+    return _lib
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.2e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1, 512, 256), (77, 132, 128), (1024, 1152, 1152)])
+def test_gemm_bias_residual(dev, dtype, tol, M, N, K):
+    ops = _ops()
+    torch.manual_seed(M * 7 + N)
+    a = torch.randn(M, K).to(dtype)
+    w = (torch.randn(N, K) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N).to(dtype)
+    r = torch.randn(M, N).to(dtype)
+    ref = a.float() @ w.float().t() + b.float() + r.float()
+    out = ops.gemm(a.to(dev), w.to(dev), b.to(dev), residual=r.to(dev))
+    assert out.dtype == dtype
+    assert rel_err(out.float(), ref) < tol
+
+
+def test_gemm_integer_exact(dev):
+    """MFMA fragment/layout check with exactly representable data and an asymmetric W"""
+    ops = _ops()
+    M, N, K = 256, 256, 128
+    a = torch.randint(-3, 4, (M, K)).float()
+    w = (torch.arange(N)[:, None] % 5 - 2).float() * torch.randint(0, 2, (N, K)).float() + (torch.arange(K)[None, :] % 3).float()
+    ref = a @ w.t()
+    out = ops.gemm(a.to(dev).bfloat16(), w.to(dev).bfloat16(), out_f32=True)
+    assert torch.equal(out.cpu(), ref)
+    out32 = ops.gemm(a.to(dev), w.to(dev))
+    assert torch.equal(out32.cpu(), ref)
+
+
+@pytest.mark.parametrize("act", ["tanh", "erf"])
+def test_gemm_gelu(dev, act):
+    ops, L = _ops(), _L()
+    torch.manual_seed(1)
+    a = torch.randn(200, 128).bfloat16()
+    w = (torch.randn(256, 128) / 11).bfloat16()
+    b = torch.randn(256).bfloat16()
+    pre = a.float() @ w.float().t() + b.float()
+    ref = F.gelu(pre, approximate="tanh") if act == "tanh" else F.gelu(pre)
+    out = ops.gemm(a.to(dev), w.to(dev), b.to(dev), act=L.ACT_GELU_TANH if act == "tanh" else L.ACT_GELU_ERF)
+    assert rel_err(out.float(), ref) < 1.2e-2
+
+
+@pytest.mark.parametrize("M", [1, 130])
+def test_gemm_swiglu(dev, M):
+    ops, L = _ops(), _L()
+    torch.manual_seed(2)
+    H, I = 128, 192
+    x = torch.randn(M, H).bfloat16()
+    wg = (torch.randn(I, H) / 11).bfloat16()
+    wu = (torch.randn(I, H) / 11).bfloat16()
+    ref = F.silu(x.float() @ wg.float().t()) * (x.float() @ wu.float().t())
+    gu = torch.stack([wg, wu], dim=1).reshape(2 * I, H).contiguous()
+    out = ops.gemm(x.to(dev), gu.to(dev), act=L.ACT_SWIGLU)
+    assert out.shape == (M, I)
+    assert rel_err(out.float(), ref) < 1.2e-2
+
+
+@pytest.mark.parametrize("M", [1, 96])
+def test_gemm_rope_epilogue(dev, M):
+    """columns [0, rope_cols) rotated as rotate_half pairs after the (d, d+hd/2) row interleave"""
+    ops = _ops()
+    torch.manual_seed(3)
+    hd, heads, K = 72, 2, 128
+    N = 3 * heads * hd  # q | k | v, v not rotated
+    x = torch.randn(M, K).bfloat16()
+    w = (torch.randn(N, K) / 11).bfloat16()
+    b = torch.randn(N).bfloat16()
+    ang = torch.rand(M, hd // 2) * 6.0
+    y = (x.float() @ w.float().t() + b.float()).view(M, 3 * heads, hd)
+    cos = torch.cat([ang.cos(), ang.cos()], -1)[:, None, :]
+    sin = torch.cat([ang.sin(), ang.sin()], -1)[:, None, :]
+    rot = torch.cat([-y[..., hd // 2:], y[..., :hd // 2]], -1)
+    ref = y.clone()
+    ref[:, :2 * heads] = (y * cos + rot * sin)[:, :2 * heads]
+    # pack: within each q/k head, new row 2i <- d=i, 2i+1 <- d=i+hd/2
+    perm = torch.arange(hd).view(2, hd // 2).t().reshape(-1)
+    wp = w.view(3 * heads, hd, K).clone()
+    bp = b.view(3 * heads, hd).clone()
+    wp[:2 * heads] = wp[:2 * heads][:, perm]
+    bp[:2 * heads] = bp[:2 * heads][:, perm]
+    out = ops.gemm(x.to(dev), wp.reshape(N, K).contiguous().to(dev), bp.reshape(N).contiguous().to(dev),
+                   rope_cos=ang.cos().contiguous().to(dev), rope_sin=ang.sin().contiguous().to(dev),
+                   rope_cols=2 * heads * hd, head_dim=hd)
+    refp = ref.clone()
+    refp[:, :2 * heads] = ref[:, :2 * heads][:, :, perm]
+    assert rel_err(out.float().view(M, 3 * heads, hd), refp) < 1.2e-2
+
+
+def _attn_ref(q, k, v, hq, hkv, hd, cu=None, causal=False, q_pos0=0, row_lo=None, row_hi=None, bias=0.0):
+    Lq, Lk = q.shape[0], k.shape[0]
+    q = q.float().view(Lq, hq, hd).transpose(0, 1)
+    k = k.float().view(Lk, hkv, hd).transpose(0, 1).repeat_interleave(hq // hkv, 0)
+    v = v.float().view(Lk, hkv, hd).transpose(0, 1).repeat_interleave(hq // hkv, 0)
+    s = q @ k.transpose(1, 2) / math.sqrt(hd)
+    qi, kj = torch.arange(Lq)[:, None], torch.arange(Lk)[None, :]
+    allow = torch.ones(Lq, Lk, dtype=torch.bool)
+    if cu is not None:
+        seg_q = torch.bucketize(qi, cu[1:], right=True)
+        seg_k = torch.bucketize(kj, cu[1:], right=True)
+        allow &= seg_q == seg_k
+    if causal:
+        allow &= kj <= qi + q_pos0
+    if row_lo is not None:
+        s = s + ((kj >= row_lo[:, None]) & (kj < row_hi[:, None])).float() * bias
+    s = s.masked_fill(~allow, float("-inf"))
+    return (F.softmax(s, -1) @ v).transpose(0, 1).reshape(Lq, hq * hd)
+
+
+@pytest.mark.parametrize("hd,heads,lens", [(72, 2, [256, 256]), (72, 3, [200, 200, 200]), (72, 2, [924]), (72, 1, [37, 130])])
+def test_attention_block_diag_bf16(dev, hd, heads, lens):
+    ops = _ops()
+    torch.manual_seed(sum(lens))
+    n = sum(lens)
+    qkv = torch.randn(n, 3 * heads * hd).bfloat16()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    H = heads * hd
+    ref = _attn_ref(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], heads, heads, hd, cu=cu.long())
+    g = qkv.to(dev)
+    out = ops.attention(g[:, :H], g[:, H:2 * H], g[:, 2 * H:], hq=heads, hkv=heads, head_dim=hd,
+                        cu_seqlens=cu.to(dev), max_seqlen=max(lens))
+    assert rel_err(out.float(), ref) < 1.5e-2
+
+
+def test_attention_integer_exact(dev):
+    """layout check: one-hot attention (huge scale) must copy integer V rows exactly"""
+    ops = _ops()
+    hd, n = 128, 192
+    torch.manual_seed(0)
+    tgt = torch.randperm(n)
+    # unique two-hot keys: q = 64*k[tgt] scores 128 on its target and <= 64 elsewhere
+    k = torch.zeros(n, hd)
+    k[torch.arange(n), torch.arange(n) % 120] = 1.0
+    k[torch.arange(n), 120 + torch.arange(n) // 120] = 1.0
+    q = k[tgt] * 64.0
+    v = torch.randint(-8, 9, (n, hd)).float()
+    out = ops.attention(q.bfloat16().to(dev), k.bfloat16().to(dev), v.bfloat16().to(dev), hq=1, hkv=1, head_dim=hd,
+                        scale=1.0)
+    assert torch.equal(out.float().cpu(), v[tgt])
+
+
+@pytest.mark.parametrize("S,pos0", [(200, 0), (130, 77), (1, 300)])
+def test_attention_causal_gqa_bf16(dev, S, pos0):
+    ops = _ops()
+    torch.manual_seed(S)
+    hd, hq, hkv = 128, 4, 2
+    ctx = pos0 + S
+    q = torch.randn(S, hq * hd).bfloat16()
+    k = torch.randn(ctx, hkv * hd).bfloat16()
+    v = torch.randn(ctx, hkv * hd).bfloat16()
+    ref = _attn_ref(q, k, v, hq, hkv, hd, causal=True, q_pos0=pos0)
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_pos0=pos0)
+    assert rel_err(out.float(), ref) < 1.5e-2
+    if S == 1:
+        out2 = ops.attention(q.to(dev), k.to(dev), v.to(dev), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_pos0=pos0,
+                             nsplit=3)
+        assert rel_err(out2.float(), ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("dtype,tol,rowwise", [(torch.bfloat16, 1.5e-2, False), (torch.float32, 1e-5, True)])
+def test_attention_eager_global_bias(dev, dtype, tol, rowwise):
+    ops = _ops()
+    torch.manual_seed(5)
+    hd, heads, lens = 72, 2, [64, 64, 64]
+    n = sum(lens)
+    H = heads * hd
+    qkv = torch.randn(n, 3 * H).to(dtype)
+    lo = torch.tensor([64 * (i // 64) for i in range(n)], dtype=torch.int32)
+    hi = lo + 64
+    ref = _attn_ref(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], heads, heads, hd, row_lo=lo.long(), row_hi=hi.long(), bias=1.0)
+    g = qkv.to(dev)
+    out = ops.attention(g[:, :H], g[:, H:2 * H], g[:, 2 * H:], hq=heads, hkv=heads, head_dim=hd, row_lo=lo.to(dev),
+                        row_hi=hi.to(dev), bias=1.0, force_rowwise=rowwise)
+    assert rel_err(out.float(), ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float32, 1e-5)])
+@pytest.mark.parametrize("H", [144, 1152, 3584])
+def test_norms(dev, dtype, tol, H):
+    ops = _ops()
+    torch.manual_seed(H)
+    x = (torch.randn(37, H) * 2 + 0.3).to(dtype)
+    g = (1 + 0.1 * torch.randn(H)).to(dtype)
+    b = (0.1 * torch.randn(H)).to(dtype)
+    ref = F.layer_norm(x.float(), (H,), g.float(), b.float(), 1e-6)
+    assert rel_err(ops.layernorm(x.to(dev), g.to(dev), b.to(dev)).float(), ref) < tol
+    xf = x.float()
+    ref = g.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert rel_err(ops.rmsnorm(x.to(dev), g.to(dev)).float(), ref) < tol
+    xm = x[:36]
+    ref = F.layer_norm(xm.float(), (H,), g.float(), b.float(), 1e-6).view(9, 4, H).mean(1)
+    assert rel_err(ops.ln_merge(xm.contiguous().to(dev), g.to(dev), b.to(dev), 4).float(), ref) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pixdiff_mask_matches_torch_semantics(dev, dtype):
+    """bit-exact against the torch expression of cogreasoner_chat.py:407-414 run in the same dtype"""
+    ops = _ops()
+    torch.manual_seed(11)
+    t, P, E = 6, 20, 2352
+    base = torch.rand(1, P, E) * 2 - 1
+    pix = base.repeat(t, 1, 1)
+    pix[1] += 0.002 * torch.randn(P, E)           # tiny change: mostly below threshold
+    pix[2, :5] += 0.5 * torch.randn(5, E)         # big change on 5 tokens
+    pix[4] = pix[3]                               # identical frame -> min_tokens kicks in
+    pix = pix.to(dtype)
+    diff = torch.abs(pix[1:] - pix[:-1]).mean(dim=-1) * 255
+    diff = torch.cat([torch.full_like(diff[0:1], 1.1), diff], dim=0)
+    m = diff > 0.1
+    pad = torch.nonzero(m.sum(dim=1) < 1)[:, 0]
+    m[pad, :1] = 1
+    minor = torch.zeros(t, dtype=torch.uint8)
+    minor[5] = 1
+    m[5, 0] = True
+    m[5, 1:] = False
+    out = ops.pixdiff_mask(pix.reshape(-1, 588).contiguous().to(dev), t, P, minor=minor.to(dev))
+    assert torch.equal(out.cpu().bool(), m.flatten())
+    assert 0 < int(m.sum()) < m.numel()
+
+
+def test_frame_mean_gather_mean_cosine(dev):
+    ops = _ops()
+    torch.manual_seed(12)
+    P, D, T = 7, 256, 5
+    f = torch.randn(T * P, D).bfloat16()
+    ref = f.view(T, P, D).clone()
+    for i in (1, 3):
+        ref[i, 0] = ref[i].mean(dim=0)
+    g = f.to(dev).clone()
+    ops.frame_mean_to_slot0(g, P, torch.tensor([1, 3], dtype=torch.int32, device=dev))
+    assert rel_err(g.float().cpu(), ref.view(-1, D).float()) < 8e-3
+    ta, tb = torch.randn(50, D).bfloat16(), torch.randn(9, D).bfloat16()
+    idx = torch.tensor([3, -1, 49, -9, 0, -4], dtype=torch.int64)
+    out = ops.gather_rows(ta.to(dev), tb.to(dev), idx.to(dev))
+    ref = torch.stack([ta[i] if i >= 0 else tb[-i - 1] for i in idx.tolist()])
+    assert torch.equal(out.cpu(), ref)
+    x = torch.randn(333, D).bfloat16()
+    assert rel_err(ops.mean_rows(x.to(dev)), x.float().mean(0)) < 1e-5
+    a, b = torch.randn(D), torch.randn(6, D)
+    assert rel_err(ops.cosine(a.to(dev), b.to(dev)), F.cosine_similarity(a[None], b, dim=1)) < 1e-5
+
+
+def test_logits_ops(dev):
+    ops = _ops()
+    torch.manual_seed(13)
+    n = 152064
+    lg = torch.randn(n)
+    lg[777] = lg.max() + 1
+    assert int(ops.argmax(lg.to(dev))) == 777
+    prev = torch.tensor([5, 777, 5, 42], dtype=torch.int64)
+    ref = lg.clone()
+    g = ref[prev]
+    ref[prev] = torch.where(g < 0, g * 1.05, g / 1.05)
+    ref = ref / 0.7
+    x = lg.to(dev).clone()
+    ops.logits_process(x, prev.to(dev), 1.05, None, 0.7)
+    assert torch.allclose(x.cpu(), ref, rtol=1e-6, atol=0)
+    allowed = torch.tensor([11, 15, 16, 58, 60, 151645], dtype=torch.int32)
+    x = lg.to(dev).clone()
+    ops.logits_process(x, None, 1.0, allowed.to(dev), 1.0)
+    refm = torch.full_like(lg, float("-inf"))
+    refm[allowed.long()] = lg[allowed.long()]
+    assert torch.equal(x.cpu(), refm)
+    val, idx = ops.topk(lg.to(dev), 20)
+    rv, ri = torch.topk(lg, 20)
+    assert torch.equal(val.cpu(), rv) and torch.equal(idx.cpu().long(), ri)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_kmeans_steps(dev, dtype):
+    ops = _ops()
+    torch.manual_seed(14)
+    T, PD, K = 40, 2 * 1024 + 512 + 8, 5
+    cent = torch.randn(K, PD) * 3
+    lab = torch.randint(0, K, (T,))
+    x = (cent[lab] + 0.3 * torch.randn(T, PD)).to(dtype)
+    ts = torch.arange(T).float()
+    ws = ops.kmeans_workspace(T, PD, K, dev)
+    rows = torch.tensor([0, 7, 13, 21, 30], dtype=torch.int32)
+    xg = x.to(dev)
+    d2 = ops.kmeans_sqdist(xg, None, rows.to(dev), K, ws)
+    ref = torch.cdist(x.double(), x[rows.long()].double()) ** 2
+    assert rel_err(d2, ref) < 1e-5
+    cf = x[rows.long()].float().contiguous()
+    ct = ts[rows.long()].contiguous()
+    d2b = ops.kmeans_sqdist(xg, cf.to(dev), None, K, ws)
+    assert rel_err(d2b, ref) < 1e-5
+    assign, counts = ops.kmeans_assign(d2b, ts.to(dev), ct.to(dev), 2.0)
+    df = ref.float().sqrt()
+    dtm = (ts[:, None] - ct[None]).abs()
+    nf = (df - df.min(1, keepdim=True).values) / (df.max(1, keepdim=True).values - df.min(1, keepdim=True).values)
+    nt = (dtm - dtm.min(1, keepdim=True).values) / (dtm.max(1, keepdim=True).values - dtm.min(1, keepdim=True).values)
+    ra = torch.sqrt(nf ** 2 + 2 * nt ** 2).argmin(1)
+    assert torch.equal(assign.cpu(), ra)
+    assert torch.equal(counts.cpu().long(), torch.bincount(ra, minlength=K))
+    # force an empty cluster to exercise the reseed path
+    a2 = ra.clone()
+    a2[a2 == 4] = 0
+    reseed = torch.tensor([0, 0, 0, 0, 17], dtype=torch.int32)
+    cg, ctg = cf.to(dev).clone(), ct.to(dev).clone()
+    shift = ops.kmeans_update(xg, ts.to(dev), a2.to(dev), reseed.to(dev), cg, ctg, ws)
+    ncf, nct = torch.zeros_like(cf), torch.zeros_like(ct)
+    for i in range(K):
+        m = a2 == i
+        if m.any():
+            ncf[i] = x.float()[m].mean(0)
+            nct[i] = ts[m].mean()
+        else:
+            ncf[i] = x.float()[17]
+            nct[i] = ts[17]
+    rs = torch.norm(ncf - cf, dim=1).sum() + torch.norm(nct - ct)
+    assert rel_err(cg, ncf) < 1e-5 and rel_err(ctg, nct) < 1e-6
+    assert abs(float(shift) - float(rs)) / float(rs) < 1e-5
