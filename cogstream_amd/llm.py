@@ -1,0 +1,122 @@
+"""Host mirror of the Qwen2 seams the reference calls (transformers, pinned 4.46.3):
+self.get_model()(inputs_embeds=..., attention_mask=...) (model/cogreasoner_chat.py:312-316,322) and
+super().generate(inputs_embeds=...) (:802-807), computing through cogs_llm_forward."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .runtime import get_handle
+from .weights import LlmConfig, PackedLlm
+
+
+class KVCache:
+    def __init__(self, cfg: LlmConfig, max_len: int, dtype, device):
+        kvd = cfg.num_key_value_heads * cfg.head_dim
+        self.k = torch.empty(cfg.num_hidden_layers, max_len, kvd, device=device, dtype=dtype)
+        self.v = torch.empty_like(self.k)
+        self.struct = L.KV(self.k.data_ptr(), self.v.data_ptr(), max_len, 0)
+
+    @property
+    def len(self) -> int:
+        return self.struct.len
+
+    def reset(self, length: int = 0):
+        self.struct.len = length
+
+
+class Qwen2Engine:
+    def __init__(self, state: Dict[str, torch.Tensor], cfg: LlmConfig, dtype=torch.bfloat16, device="cuda"):
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.handle = get_handle(self.device)
+        self.packed = PackedLlm(state, cfg, dtype, self.device)
+        L.check(L.lib.cogs_llm_load(self.handle.h, C.byref(self.packed.struct)), "cogs_llm_load")
+
+    def new_cache(self, max_len: int) -> KVCache:
+        return KVCache(self.cfg, max_len, self.dtype, self.device)
+
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        return ops.gather_rows(self.packed.embed, None, ids.reshape(-1).to(self.device, torch.int64))
+
+    def forward(self, embeds: torch.Tensor, cache: Optional[KVCache] = None, *, want_logits: bool = True,
+                want_pooled: bool = False, want_hidden: bool = False):
+        """returns dict(logits fp32 [vocab] | pooled fp32 [H] | hidden [S,H])"""
+        embeds = embeds.contiguous()
+        S = embeds.shape[0]
+        ctx = S + (cache.len if cache is not None else 0)
+        nbytes = C.c_size_t()
+        L.check(L.lib.cogs_llm_workspace_bytes(self.handle.h, S, ctx, C.byref(nbytes)), "cogs_llm_workspace_bytes")
+        ws = self.handle.workspace("llm", nbytes.value)
+        out = {}
+        logits = torch.empty(self.cfg.vocab_size, device=self.device, dtype=torch.float32) if want_logits else None
+        pooled = torch.empty(self.cfg.hidden_size, device=self.device, dtype=torch.float32) if want_pooled else None
+        hidden = torch.empty(S, self.cfg.hidden_size, device=self.device, dtype=self.dtype) if want_hidden else None
+        L.check(L.lib.cogs_llm_forward(self.handle.h, L.current_stream(), embeds.data_ptr(), S,
+                                       C.byref(cache.struct) if cache is not None else None, L.ptr(logits),
+                                       L.ptr(pooled), L.ptr(hidden), ws.data_ptr(), ws.numel()), "cogs_llm_forward")
+        if want_logits:
+            out["logits"] = logits
+        if want_pooled:
+            out["pooled"] = pooled
+        if want_hidden:
+            out["hidden"] = hidden
+        return out
+
+    def generate(self, embeds: torch.Tensor, *, max_new_tokens: int, eos_token_id: Sequence[int] = (),
+                 do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
+                 repetition_penalty: float = 1.0, allowed_ids: Optional[Sequence[int]] = None,
+                 prompt_ids: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
+                 cache: Optional[KVCache] = None, ignore_eos: bool = False) -> List[int]:
+        """GenerationMixin.generate with inputs_embeds: prefill, then one cogs_llm_forward per token.
+        Returns the NEW token ids only. Logits processors run in HF order:
+        repetition penalty -> custom (allowed-id mask) -> temperature -> top-k -> top-p."""
+        S = embeds.shape[0]
+        if cache is None:
+            cache = self.new_cache(S + max_new_tokens)
+        res = self.forward(embeds, cache)
+        allowed = (torch.tensor(list(allowed_ids), dtype=torch.int32, device=self.device) if allowed_ids is not None else None)
+        seen: List[int] = [int(t) for t in prompt_ids.reshape(-1).tolist()] if prompt_ids is not None else []
+        out: List[int] = []
+        eos = set(int(e) for e in eos_token_id)
+        for step in range(max_new_tokens):
+            logits = res["logits"]
+            prev = torch.tensor(seen, dtype=torch.int64, device=self.device) if (seen and repetition_penalty != 1.0) else None
+            if prev is not None or allowed is not None or (do_sample and temperature != 1.0):
+                ops.logits_process(logits, prev, repetition_penalty, allowed, temperature if do_sample else 1.0)
+            if do_sample:
+                tok = self._sample(logits, top_k, top_p, generator)
+            else:
+                tok = int(ops.argmax(logits))
+            out.append(tok)
+            seen.append(tok)
+            if tok in eos and not ignore_eos:
+                break
+            if step + 1 < max_new_tokens:
+                res = self.forward(self.embed_tokens(torch.tensor([tok])), cache)
+        return out
+
+    def _sample(self, logits: torch.Tensor, top_k: int, top_p: float, generator) -> int:
+        """TopKLogitsWarper + TopPLogitsWarper + multinomial on the k survivors (k = 20 by default,
+        model/generation_config.json:9-10); the draw uses the host generator like the reference's sampler."""
+        k = top_k if top_k and top_k > 0 else 64
+        val, idx = ops.topk(logits, k)
+        val, idx = val.cpu(), idx.cpu()
+        keep = idx >= 0
+        val, idx = val[keep], idx[keep]
+        probs = torch.softmax(val, dim=-1)
+        if top_p < 1.0:
+            # HF: sort ascending, drop tokens whose cumulative prob <= 1 - top_p, always keep the best one
+            sp, order = torch.sort(probs, descending=False)
+            cum = sp.cumsum(-1)
+            remove = cum <= (1 - top_p)
+            remove[-1] = False
+            drop = torch.zeros_like(remove)
+            drop[order] = remove
+            val = val.masked_fill(drop, float("-inf"))
+            probs = torch.softmax(val, dim=-1)
+        j = int(torch.multinomial(probs, 1, generator=generator))
+        return int(idx[j])

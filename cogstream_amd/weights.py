@@ -1,0 +1,228 @@
+"""Weight containers and the one-off packing into the layouts the HIP kernels expect.
+
+Names follow the reference checkpoint (model/model.safetensors.index.json; module tree
+model/cogreasoner_chat.py:214-248,591-598): model.vision_encoder.*, model.mm_projector.readout.{0,2}.*,
+model.embed_tokens, model.layers.N.*, model.norm, lm_head. Packing rules are documented in include/cogs.h:
+  * q/k rows of every head interleaved as rotary pairs (d, d+hd/2) -> (2i, 2i+1);
+  * q,k,v stacked into one [.., hidden] matrix; gate/up rows interleaved;
+  * K dimensions zero-padded to the GEMM slab (64 bf16 / 32 fp32 elements).
+torch is used here for tensor storage and the one-time reshuffles only."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List
+
+import torch
+
+from . import _lib as L
+from .ops import k_slab, pad_cols
+
+
+@dataclass
+class VisionConfig:
+    """model/config.json:35-42 (vision_encoder_config) + configuration_videollama3_encoder.py:22-49"""
+    hidden_size: int = 1152
+    intermediate_size: int = 4304
+    num_hidden_layers: int = 27
+    num_attention_heads: int = 16
+    num_channels: int = 3
+    patch_size: int = 14
+    layer_norm_eps: float = 1e-6
+
+    @property
+    def patch_dim(self) -> int:
+        return self.num_channels * self.patch_size * self.patch_size
+
+
+@dataclass
+class LlmConfig:
+    """model/config.json:12-43"""
+    hidden_size: int = 3584
+    intermediate_size: int = 18944
+    num_hidden_layers: int = 28
+    num_attention_heads: int = 28
+    num_key_value_heads: int = 4
+    vocab_size: int = 152064
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    image_token_index: int = 151665
+    eos_token_id: int = 151645
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+
+def rope_perm(hd: int) -> torch.Tensor:
+    """new row 2i <- old i, 2i+1 <- old i + hd/2"""
+    return torch.arange(hd).view(2, hd // 2).t().reshape(-1)
+
+
+def _perm_heads(w: torch.Tensor, heads: int, hd: int) -> torch.Tensor:
+    p = rope_perm(hd).to(w.device)
+    shp = w.shape
+    return w.reshape(heads, hd, *shp[1:])[:, p].reshape(shp)
+
+
+def _pad_rows(x: torch.Tensor, rows: int) -> torch.Tensor:
+    if x.shape[0] == rows:
+        return x.contiguous()
+    out = x.new_zeros(rows, *x.shape[1:])
+    out[: x.shape[0]] = x
+    return out
+
+
+class PackedVit:
+    def __init__(self, state: Dict[str, torch.Tensor], cfg: VisionConfig, dtype=torch.bfloat16, device="cuda"):
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        slab = k_slab(dtype)
+        H, I, hd = cfg.hidden_size, cfg.intermediate_size, cfg.hidden_size // cfg.num_attention_heads
+        self.inter_pad = (I + slab - 1) // slab * slab
+        self.patch_pad = (cfg.patch_dim + slab - 1) // slab * slab
+        cv = lambda t: t.to(device=self.device, dtype=dtype)
+        self.keep: List[torch.Tensor] = []
+
+        def hold(t):
+            t = t.contiguous()
+            self.keep.append(t)
+            return t
+
+        g = lambda k: cv(state[k])
+        self.patch_w = hold(pad_cols(g("embeddings.patch_embedding.weight").reshape(H, -1), slab))
+        self.patch_b = hold(g("embeddings.patch_embedding.bias"))
+        self.post_g = hold(g("post_layernorm.weight"))
+        self.post_b = hold(g("post_layernorm.bias"))
+        self.layers = (L.VitLayer * cfg.num_hidden_layers)()
+        for i in range(cfg.num_hidden_layers):
+            p = f"encoder.layers.{i}."
+            a = p + "self_attn."
+            qw = _perm_heads(g(a + "q_proj.weight"), cfg.num_attention_heads, hd)
+            kw = _perm_heads(g(a + "k_proj.weight"), cfg.num_attention_heads, hd)
+            qb = _perm_heads(g(a + "q_proj.bias"), cfg.num_attention_heads, hd)
+            kb = _perm_heads(g(a + "k_proj.bias"), cfg.num_attention_heads, hd)
+            lay = self.layers[i]
+            lay.ln1_g = hold(g(p + "layer_norm1.weight")).data_ptr()
+            lay.ln1_b = hold(g(p + "layer_norm1.bias")).data_ptr()
+            lay.qkv_w = hold(torch.cat([qw, kw, g(a + "v_proj.weight")], 0)).data_ptr()
+            lay.qkv_b = hold(torch.cat([qb, kb, g(a + "v_proj.bias")], 0)).data_ptr()
+            lay.o_w = hold(g(a + "out_proj.weight")).data_ptr()
+            lay.o_b = hold(g(a + "out_proj.bias")).data_ptr()
+            lay.ln2_g = hold(g(p + "layer_norm2.weight")).data_ptr()
+            lay.ln2_b = hold(g(p + "layer_norm2.bias")).data_ptr()
+            lay.fc1_w = hold(_pad_rows(g(p + "mlp.fc1.weight"), self.inter_pad)).data_ptr()
+            lay.fc1_b = hold(_pad_rows(g(p + "mlp.fc1.bias"), self.inter_pad)).data_ptr()
+            lay.fc2_w = hold(pad_cols(g(p + "mlp.fc2.weight"), slab)).data_ptr()
+            lay.fc2_b = hold(g(p + "mlp.fc2.bias")).data_ptr()
+        w = L.VitWeights()
+        w.dtype = L.dtype_code(dtype)
+        w.hidden, w.inter_pad, w.layers, w.heads = H, self.inter_pad, cfg.num_hidden_layers, cfg.num_attention_heads
+        w.patch_dim, w.patch_pad, w.ln_eps = cfg.patch_dim, self.patch_pad, cfg.layer_norm_eps
+        w.patch_w, w.patch_b = self.patch_w.data_ptr(), self.patch_b.data_ptr()
+        w.post_ln_g, w.post_ln_b = self.post_g.data_ptr(), self.post_b.data_ptr()
+        w.layer = C.cast(self.layers, C.POINTER(L.VitLayer))
+        self.struct = w
+
+
+class PackedProjector:
+    def __init__(self, state: Dict[str, torch.Tensor], dtype=torch.bfloat16, device="cuda"):
+        cv = lambda t: t.to(device=device, dtype=dtype).contiguous()
+        self.w1, self.b1 = cv(state["readout.0.weight"]), cv(state["readout.0.bias"])
+        self.w2, self.b2 = cv(state["readout.2.weight"]), cv(state["readout.2.bias"])
+        w = L.ProjWeights()
+        w.dtype = L.dtype_code(dtype)
+        w.in_dim, w.out_dim = self.w1.shape[1], self.w1.shape[0]
+        w.w1, w.b1, w.w2, w.b2 = self.w1.data_ptr(), self.b1.data_ptr(), self.w2.data_ptr(), self.b2.data_ptr()
+        self.struct = w
+        self.in_dim, self.out_dim = w.in_dim, w.out_dim
+
+
+class PackedLlm:
+    def __init__(self, state: Dict[str, torch.Tensor], cfg: LlmConfig, dtype=torch.bfloat16, device="cuda"):
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        hd, hq, hkv = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads
+        cv = lambda t: t.to(device=self.device, dtype=dtype)
+        self.keep: List[torch.Tensor] = []
+
+        def hold(t):
+            t = t.contiguous()
+            self.keep.append(t)
+            return t
+
+        g = lambda k: cv(state[k])
+        self.embed = hold(g("embed_tokens.weight"))
+        self.final_norm = hold(g("norm.weight"))
+        self.lm_head = hold(g("lm_head.weight"))
+        self.layers = (L.LlmLayer * cfg.num_hidden_layers)()
+        for i in range(cfg.num_hidden_layers):
+            p = f"layers.{i}."
+            a = p + "self_attn."
+            qw, qb = _perm_heads(g(a + "q_proj.weight"), hq, hd), _perm_heads(g(a + "q_proj.bias"), hq, hd)
+            kw, kb = _perm_heads(g(a + "k_proj.weight"), hkv, hd), _perm_heads(g(a + "k_proj.bias"), hkv, hd)
+            lay = self.layers[i]
+            lay.in_ln = hold(g(p + "input_layernorm.weight")).data_ptr()
+            lay.qkv_w = hold(torch.cat([qw, kw, g(a + "v_proj.weight")], 0)).data_ptr()
+            lay.qkv_b = hold(torch.cat([qb, kb, g(a + "v_proj.bias")], 0)).data_ptr()
+            lay.o_w = hold(g(a + "o_proj.weight")).data_ptr()
+            lay.post_ln = hold(g(p + "post_attention_layernorm.weight")).data_ptr()
+            gu = torch.stack([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")], dim=1)
+            lay.gu_w = hold(gu.reshape(2 * cfg.intermediate_size, cfg.hidden_size)).data_ptr()
+            lay.down_w = hold(g(p + "mlp.down_proj.weight")).data_ptr()
+        w = L.LlmWeights()
+        w.dtype = L.dtype_code(dtype)
+        w.hidden, w.inter, w.layers = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+        w.heads, w.kv_heads, w.head_dim, w.vocab = hq, hkv, hd, cfg.vocab_size
+        w.rms_eps, w.rope_theta = cfg.rms_norm_eps, cfg.rope_theta
+        w.final_norm, w.lm_head = self.final_norm.data_ptr(), self.lm_head.data_ptr()
+        w.layer = C.cast(self.layers, C.POINTER(L.LlmLayer))
+        self.struct = w
+
+
+# ---- random initialisation at arbitrary dimensions (no checkpoints are reachable: README.md:56-58) ----
+
+def random_vit_state(cfg: VisionConfig, seed: int = 0, device="cpu", dtype=torch.float32, std: float = 0.02):
+    g = torch.Generator(device=device).manual_seed(seed)
+    r = lambda *s: (torch.randn(*s, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    st = {
+        "embeddings.patch_embedding.weight": r(H, cfg.num_channels, cfg.patch_size, cfg.patch_size),
+        "embeddings.patch_embedding.bias": r(H),
+        "post_layernorm.weight": 1 + r(H), "post_layernorm.bias": r(H),
+    }
+    for i in range(cfg.num_hidden_layers):
+        p = f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            st[p + f"self_attn.{n}.weight"] = r(H, H)
+            st[p + f"self_attn.{n}.bias"] = r(H)
+        for n in ("layer_norm1", "layer_norm2"):
+            st[p + n + ".weight"] = 1 + r(H)
+            st[p + n + ".bias"] = r(H)
+        st[p + "mlp.fc1.weight"], st[p + "mlp.fc1.bias"] = r(I, H), r(I)
+        st[p + "mlp.fc2.weight"], st[p + "mlp.fc2.bias"] = r(H, I), r(H)
+    return st
+
+
+def random_proj_state(in_dim: int, out_dim: int, seed: int = 1, device="cpu", dtype=torch.float32, std: float = 0.02):
+    g = torch.Generator(device=device).manual_seed(seed)
+    r = lambda *s: (torch.randn(*s, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+    return {"readout.0.weight": r(out_dim, in_dim), "readout.0.bias": r(out_dim),
+            "readout.2.weight": r(out_dim, out_dim), "readout.2.bias": r(out_dim)}
+
+
+def random_llm_state(cfg: LlmConfig, seed: int = 2, device="cpu", dtype=torch.float32, std: float = 0.02):
+    g = torch.Generator(device=device).manual_seed(seed)
+    r = lambda *s: (torch.randn(*s, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+    H, I, hd = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+    kvd = cfg.num_key_value_heads * hd
+    st = {"embed_tokens.weight": r(cfg.vocab_size, H), "norm.weight": 1 + r(H), "lm_head.weight": r(cfg.vocab_size, H)}
+    for i in range(cfg.num_hidden_layers):
+        p = f"layers.{i}."
+        st[p + "input_layernorm.weight"] = 1 + r(H)
+        st[p + "post_attention_layernorm.weight"] = 1 + r(H)
+        st[p + "self_attn.q_proj.weight"], st[p + "self_attn.q_proj.bias"] = r(H, H), r(H)
+        st[p + "self_attn.k_proj.weight"], st[p + "self_attn.k_proj.bias"] = r(kvd, H), r(kvd)
+        st[p + "self_attn.v_proj.weight"], st[p + "self_attn.v_proj.bias"] = r(kvd, H), r(kvd)
+        st[p + "self_attn.o_proj.weight"] = r(H, H)
+        st[p + "mlp.gate_proj.weight"], st[p + "mlp.up_proj.weight"] = r(I, H), r(I, H)
+        st[p + "mlp.down_proj.weight"] = r(H, I)
+    return st

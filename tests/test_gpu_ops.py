@@ -150,11 +150,11 @@ def test_attention_integer_exact(dev):
     hd, n = 128, 192
     torch.manual_seed(0)
     tgt = torch.randperm(n)
-    # unique two-hot keys: q = 64*k[tgt] scores 128 on its target and <= 64 elsewhere
+    # unique two-hot keys: q = 256*k[tgt] scores 512 on its target and <= 256 elsewhere (others underflow to 0)
     k = torch.zeros(n, hd)
     k[torch.arange(n), torch.arange(n) % 120] = 1.0
     k[torch.arange(n), 120 + torch.arange(n) // 120] = 1.0
-    q = k[tgt] * 64.0
+    q = k[tgt] * 256.0
     v = torch.randint(-8, 9, (n, hd)).float()
     out = ops.attention(q.bfloat16().to(dev), k.bfloat16().to(dev), v.bfloat16().to(dev), hq=1, hkv=1, head_dim=hd,
                         scale=1.0)
