@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: frames/sec encoded (+ answer tokens/sec),
+64-frame 480p clip, VideoLLaMA3-7B dimensions, bf16 (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One STEP = one pass of the encoder stage over the clip with pixel_values already resident in HBM:
+cogs_vit_encode (patch-embed GEMM, 27 x {LN, QKV GEMM+RoPE, per-frame attention, out-proj, LN, MLP},
+post-LN + 2x2 merge) + cogs_project -- SURVEY.md section 8(d) "frames/sec encoded = T / t(A1..A7)".
+N > 1 (strong scaling, the clip's frames are sharded): each rank encodes T/N frames, one RCCL all-gather
+reassembles the [M,1152] visual tokens, every rank then runs the projector; time = max over ranks.
+
+The same JSON line also carries, measured after the timed steps on rank 0:
+  answer_tokens_per_s   greedy decode rate of the Qwen2-7B path (prefill of the full ~15k-token
+                        interleaved prompt, then 128 tokens, EOS ignored), e2e_s the whole answer latency;
+  roofline              the dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of the encoder's GEMM
+                        launches / their summed duration, measured live with HIP events on the launch stream;
+  cpu_baseline          the oracle (CPU fp32 restatement of the reference) timed on this box's host cores
+                        on a bounded sample of the same workload (rank 0, N = 1 only).
+Weights are random-init at the real dimensions (no checkpoint is reachable); data is synthetic."""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def vit_gemm_flops(n_patches: int, m_tokens: int, cfg, llm_hidden: int) -> float:
+    """algorithmic (unpadded) GEMM FLOPs of one encode + project"""
+    H, I, L, pd = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.patch_dim
+    return (2.0 * n_patches * L * (4 * H * H + 2 * H * I) + 2.0 * n_patches * pd * H
+            + 2.0 * m_tokens * (H * llm_hidden + llm_hidden * llm_hidden))
+
+
+def vit_attn_flops(frames: int, per_frame: int, cfg) -> float:
+    return 4.0 * cfg.num_hidden_layers * frames * per_frame * per_frame * cfg.hidden_size
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--decode-tokens", type=int, default=128)
+    ap.add_argument("--no-llm", action="store_true", help="skip the Qwen2 prefill/decode section")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--clip", default="noise", choices=["noise", "drift"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cogstream_amd import _lib as L
+    from cogstream_amd import processing
+    from cogstream_amd.vision import Projector, VisionEncoder
+    from cogstream_amd.weights import (LlmConfig, VisionConfig, random_llm_state, random_proj_state,
+                                       random_vit_state)
+
+    vcfg, lcfg = VisionConfig(), LlmConfig()
+    T = args.frames
+    assert T % world == 0, "frames must divide over the ranks"
+
+    # ---- synthetic clip -> pixel_values (host preprocessing is outside the timed region) ----
+    frames, timestamps = processing.synthetic_clip(T, kind=args.clip)
+    feats = processing.preprocess_videos([frames], merge_size=2)
+    t, gh, gw = (int(v) for v in feats["grid_sizes"][0])
+    per_frame = gh * gw
+    P = per_frame // 4
+    n_patches, m_tokens = T * per_frame, T * P
+    pix_all = torch.from_numpy(feats["pixel_values"])
+    t_loc = T // world
+    pix = pix_all[rank * t_loc * per_frame:(rank + 1) * t_loc * per_frame].to(dev, torch.bfloat16)  # answer_generate.py:70
+    grid_loc = torch.tensor([[t_loc, gh, gw]])
+    merge = torch.tensor([2])
+
+    # ---- weights (random, real dimensions) ----
+    vit_state = random_vit_state(vcfg, seed=0, device=dev, dtype=torch.bfloat16)
+    enc = VisionEncoder(vit_state, vcfg, dtype=torch.bfloat16, device=dev)
+    proj = Projector(random_proj_state(vcfg.hidden_size, lcfg.hidden_size, seed=1, device=dev, dtype=torch.bfloat16),
+                     dtype=torch.bfloat16, device=dev)
+    del vit_state
+
+    gathered = torch.empty(m_tokens, vcfg.hidden_size, device=dev, dtype=torch.bfloat16) if world > 1 else None
+
+    def step():
+        tok = enc(pix, grid_loc, merge)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, tok)
+            tok = gathered
+        return proj(tok)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mm = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms_per_step = dt / args.steps * 1e3
+    fps = T * args.steps / dt
+
+    out = {
+        "metric": "frames/sec encoded + answer tokens/sec, 64-frame clip, VideoLLaMA3-7B",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"cfg2: {T}x480x854 '{args.clip}' clip -> {gh * 14}x{gw * 14}, {n_patches} patches, "
+                               f"{m_tokens} visual tokens; ViT(1152x27, hd72)+projector(3584); random-init weights",
+                   "frames": T, "patches": n_patches, "visual_tokens": m_tokens,
+                   "parallelism": f"frames sharded over {world} GPU(s) + all-gather" if world > 1 else "single GPU"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events around every launch ----
+        h = enc.handle
+        ms = (C.c_float * 4)()
+        cnt = (C.c_int * 4)()
+        torch.cuda.synchronize()
+        L.check(L.lib.cogs_profile_begin(h.h))
+        tok = enc(pix, grid_loc, merge)
+        proj(tok if world == 1 else gathered)
+        L.check(L.lib.cogs_profile_end(h.h, L.current_stream(), ms, cnt))
+        n_loc, m_proj = t_loc * per_frame, (m_tokens if world > 1 else t_loc * P)
+        gflops = vit_gemm_flops(n_loc, m_proj, vcfg, lcfg.hidden_size)
+        gemm_ms, gemm_n = float(ms[0]), int(cnt[0])
+        ach = gflops / (gemm_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_tn_kernel<bf16> (all encoder+projector GEMM launches)",
+                           "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
+                           "flop_per_launch": gflops / max(gemm_n, 1)}
+        attn_ms = float(ms[1])
+        out["breakdown_ms"] = {"gemm": round(gemm_ms, 2), "attention": round(attn_ms, 2), "norm": round(float(ms[2]), 2),
+                               "other": round(float(ms[3]), 2)}
+        out["attention_tflops"] = round(vit_attn_flops(t_loc, per_frame, vcfg) / (attn_ms * 1e-3) / 1e12, 1)
+        total_flops = vit_gemm_flops(n_patches, m_tokens, vcfg, lcfg.hidden_size) + vit_attn_flops(T, per_frame, vcfg)
+        out["encoder_tflops"] = round(total_flops / (ms_per_step * 1e-3) / 1e12, 1)
+
+    # ---- Qwen2-7B: prefill of the interleaved prompt + greedy decode (rank 0; other ranks wait) ----
+    if rank == 0 and not args.no_llm:
+        from cogstream_amd.llm import Qwen2Engine
+        enc.handle._ws.pop("vit", None)  # release the encoder workspace
+        torch.cuda.empty_cache()
+        eng = Qwen2Engine(random_llm_state(lcfg, seed=2, device=dev, dtype=torch.bfloat16), lcfg,
+                          dtype=torch.bfloat16, device=dev)
+        torch.cuda.empty_cache()
+        # prompt layout (chat template): system(20) + per frame "Time x.0s:"(8) + P
+        # visual tokens + ","(1), question + generation prompt (~16); text rows are random embeddings
+        S = 20 + T * (8 + P + 1) + 16
+        embeds = torch.randn(S, lcfg.hidden_size, device=dev, dtype=torch.float32).mul_(0.02).to(torch.bfloat16)
+        pos = 20
+        for f in range(T):
+            embeds[pos + 8:pos + 8 + P] = mm[f * P:(f + 1) * P]
+            pos += 8 + P + 1
+        ndec = args.decode_tokens
+        # warm-up (allocations, first-touch), then the timed answer
+        eng.generate(embeds[:256], max_new_tokens=4, ignore_eos=True)
+        torch.cuda.synchronize()
+        cache = eng.new_cache(S + ndec + 8)
+        t0 = time.perf_counter()
+        res = eng.forward(embeds, cache)
+        torch.cuda.synchronize()
+        t_prefill = time.perf_counter() - t0
+        cache.reset(0)
+        t0 = time.perf_counter()
+        toks = eng.generate(embeds, max_new_tokens=ndec, repetition_penalty=1.05, ignore_eos=True, cache=cache)
+        torch.cuda.synchronize()
+        t_gen = time.perf_counter() - t0
+        t_dec = max(t_gen - t_prefill, 1e-9)
+        out["answer_tokens_per_s"] = round((len(toks) - 1) / t_dec, 2)
+        out["llm"] = {"prompt_tokens": S, "prefill_s": round(t_prefill, 4), "decode_tokens": len(toks),
+                      "decode_s": round(t_dec, 4), "prefill_tflops": round(
+                          (2.0 * S * 6.526e9 + 2.0 * S * S * lcfg.hidden_size * lcfg.num_hidden_layers / 2) / t_prefill / 1e12, 1),
+                      "decode_hbm_gbps": round((len(toks) - 1) * (2 * 7.07e9 + 57344.0 * S) / t_dec / 1e9, 1)}
+        out["e2e_s"] = round(ms_per_step * 1e-3 + t_gen, 4)
+        del eng, cache
+        torch.cuda.empty_cache()
+
+    # ---- CPU baseline: the oracle on host cores, bounded sample (rank 0, N = 1) ----
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import vision as ov
+        from cogstream_amd.weights import random_vit_state as rvs
+        ncpu = os.cpu_count() or 1
+        torch.set_num_threads(ncpu)
+        st = rvs(vcfg, seed=0, device="cpu", dtype=torch.float32)
+        nfr = 2
+        px = pix_all[:nfr * per_frame].float()
+        g = torch.tensor([[nfr, gh, gw]])
+        with torch.no_grad():
+            ov.encode(st, px[:per_frame], torch.tensor([[1, gh, gw]]), merge, heads=vcfg.num_attention_heads,
+                      layers=2)  # warm-up of the thread pool
+            t0 = time.perf_counter()
+            ov.encode(st, px, g, merge, heads=vcfg.num_attention_heads, layers=vcfg.num_hidden_layers)
+            tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(nfr / tc, 3), "unit": "frames/s", "cores": ncpu, "kind": "port",
+                               "sample": f"oracle.vision.encode (torch fp32, block-diagonal) on {nfr} frames of the same "
+                                         f"clip ({nfr * per_frame} patches, 27 layers), {tc:.1f} s"}
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,8 @@ SIGNATURES = {
     "cogs_version": (C.c_char_p, []),
     "cogs_create": (c_int, [c_int, C.POINTER(c_void_p)]),
     "cogs_destroy": (c_int, [c_void_p]),
+    "cogs_profile_begin": (c_int, [c_void_p]),
+    "cogs_profile_end": (c_int, [c_void_p, c_void_p, C.POINTER(c_float), C.POINTER(c_int)]),
     "cogs_gemm": (c_int, [c_void_p, C.POINTER(GemmDesc)]),
     "cogs_attention": (c_int, [c_void_p, C.POINTER(AttnDesc)]),
     "cogs_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),

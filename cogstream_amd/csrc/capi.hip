@@ -28,7 +28,31 @@ struct cogs_ctx {
     float* llm_inv_freq = nullptr;  // device [head_dim/2]
     // host staging kept alive across async copies
     std::vector<int32_t> h_cu, h_lo, h_hi;
+    // optional per-kernel-class event profiling (bench/roofline only)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;      // pairs
+    std::vector<int> prof_cls;
+    size_t prof_used = 0;
 };
+
+// RAII event bracket around one launch; a no-op unless cogs_profile_begin() was called
+struct ProfScope {
+    cogs_ctx* c; hipStream_t st; size_t slot = 0; bool on;
+    ProfScope(cogs_ctx* c_, hipStream_t st_, int cls) : c(c_), st(st_), on(c_->prof_on) {
+        if (!on) return;
+        if (c->prof_used * 2 + 2 > c->prof_ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            c->prof_ev.push_back(a); c->prof_ev.push_back(b);
+        }
+        slot = c->prof_used++;
+        if (c->prof_cls.size() < c->prof_used) c->prof_cls.resize(c->prof_used);
+        c->prof_cls[slot] = cls;
+        (void)hipEventRecord(c->prof_ev[2 * slot], st);
+    }
+    ~ProfScope() { if (on) (void)hipEventRecord(c->prof_ev[2 * slot + 1], st); }
+};
+#define PROF(cls) ProfScope _prof_scope(h, st, cls)
 
 namespace {
 
@@ -88,8 +112,31 @@ cogs_status cogs_create(int device, cogs_handle* out) {
     return COGS_OK;
 }
 
+cogs_status cogs_profile_begin(cogs_handle h) {
+    if (!h) return COGS_E_INVALID;
+    h->prof_on = true;
+    h->prof_used = 0;
+    return COGS_OK;
+}
+
+cogs_status cogs_profile_end(cogs_handle h, cogs_stream stream, float* ms_per_class, int* launches_per_class) {
+    if (!h || !ms_per_class || !launches_per_class) return COGS_E_INVALID;
+    h->prof_on = false;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return COGS_E_HIP;
+    for (int i = 0; i < COGS_PROF_CLASSES; ++i) { ms_per_class[i] = 0.f; launches_per_class[i] = 0; }
+    for (size_t i = 0; i < h->prof_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) != hipSuccess) return COGS_E_HIP;
+        const int cls = h->prof_cls[i];
+        if (cls >= 0 && cls < COGS_PROF_CLASSES) { ms_per_class[cls] += ms; launches_per_class[cls] += 1; }
+    }
+    h->prof_used = 0;
+    return COGS_OK;
+}
+
 cogs_status cogs_destroy(cogs_handle h) {
     if (!h) return COGS_OK;
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->vit_inv_freq) (void)hipFree(h->vit_inv_freq);
     if (h->llm_inv_freq) (void)hipFree(h->llm_inv_freq);
     delete h;
@@ -283,7 +330,7 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
             const int t = (int)grid_sizes[3 * v], gh = (int)grid_sizes[3 * v + 1], gw = (int)grid_sizes[3 * v + 2];
             const int per = gh * gw;
             if (per > max_seq) max_seq = per;
-            COGS_TRY(cogs_k_vit_rope_table(st, rc, rs, (int)row, t, gh, gw, (int)merge_sizes[v], h->vit_inv_freq, h->vit_nfreq));
+            { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_vit_rope_table(st, rc, rs, (int)row, t, gh, gw, (int)merge_sizes[v], h->vit_inv_freq, h->vit_nfreq)); }
             for (int f = 0; f < t; ++f) {
                 if (need_rows)
                     for (int r = 0; r < per; ++r) { h->h_lo[row + r] = (int32_t)row; h->h_hi[row + r] = (int32_t)(row + per); }
@@ -299,23 +346,23 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
     }
 
     // patch embed: conv2d k=s=14 == GEMM over the 588-element rows (:202-210)
-    COGS_TRY(cogs_k_pack_rows(st, pix_dtype, dt, pixel_values, w.patch_dim, xpad, w.patch_pad, (int)N, w.patch_dim, w.patch_pad));
+    { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_pack_rows(st, pix_dtype, dt, pixel_values, w.patch_dim, xpad, w.patch_pad, (int)N, w.patch_dim, w.patch_pad)); }
     {
         CogsGemm g; g.dtype = dt;
         g.A = xpad; g.lda = w.patch_pad; g.W = w.patch_w; g.ldw = w.patch_pad; g.C = x; g.ldc = H;
         g.bias = w.patch_b; g.M = (int)N; g.N = H; g.K = w.patch_pad;
-        COGS_TRY(cogs_k_gemm(st, g));
+        { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
     }
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < w.layers; ++l) {
         const cogs_vit_layer& L = h->vit_layers[l];
-        COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln1_g, L.ln1_b, (int)N, H, w.ln_eps));
+        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln1_g, L.ln1_b, (int)N, H, w.ln_eps)); }
         {
             CogsGemm g; g.dtype = dt;
             g.A = ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = 3 * H;
             g.bias = L.qkv_b; g.M = (int)N; g.N = 3 * H; g.K = H;
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = 2 * H; g.head_dim = hd;
-            COGS_TRY(cogs_k_gemm(st, g));
+            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         {
             CogsAttn a; a.dtype = dt;
@@ -324,26 +371,26 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
             a.q_len = (int)N; a.kv_len = (int)N; a.hq = a.hkv = w.heads; a.head_dim = hd; a.scale = scale;
             if (attn_mode == COGS_ATTN_REF_EAGER_GLOBAL) { a.row_lo = lo; a.row_hi = hi; a.bias = 1.0f; }
             else { a.cu_seqlens = cu; a.nseg = nframes; a.max_seqlen = max_seq; }
-            COGS_TRY(cogs_k_attention(st, a));
+            { PROF(COGS_PROF_ATTN); COGS_TRY(cogs_k_attention(st, a)); }
         }
         {
             CogsGemm g; g.dtype = dt;
             g.A = att; g.lda = H; g.W = L.o_w; g.ldw = H; g.C = x; g.ldc = H;
             g.bias = L.o_b; g.residual = x; g.ldr = H; g.M = (int)N; g.N = H; g.K = H;
-            COGS_TRY(cogs_k_gemm(st, g));
+            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
-        COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln2_g, L.ln2_b, (int)N, H, w.ln_eps));
+        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln2_g, L.ln2_b, (int)N, H, w.ln_eps)); }
         {
             CogsGemm g; g.dtype = dt;
             g.A = ln; g.lda = H; g.W = L.fc1_w; g.ldw = H; g.C = big; g.ldc = w.inter_pad;
             g.bias = L.fc1_b; g.M = (int)N; g.N = w.inter_pad; g.K = H; g.act = COGS_ACT_GELU_TANH;
-            COGS_TRY(cogs_k_gemm(st, g));
+            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         {
             CogsGemm g; g.dtype = dt;
             g.A = big; g.lda = w.inter_pad; g.W = L.fc2_w; g.ldw = w.inter_pad; g.C = x; g.ldc = H;
             g.bias = L.fc2_b; g.residual = x; g.ldr = H; g.M = (int)N; g.N = H; g.K = w.inter_pad;
-            COGS_TRY(cogs_k_gemm(st, g));
+            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
     }
     // post_layernorm + per-video 2x2 merge (:482-510)
@@ -352,8 +399,8 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
         for (int v = 0; v < V; ++v) {
             const int64_t n = grid_sizes[3 * v] * grid_sizes[3 * v + 1] * grid_sizes[3 * v + 2];
             const int grp = (int)(merge_sizes[v] * merge_sizes[v]);
-            COGS_TRY(cogs_k_ln_merge(st, dt, (char*)x + (size_t)row * H * es, (char*)out_tokens + (size_t)orow * H * es,
-                                     w.post_ln_g, w.post_ln_b, (int)(n / grp), grp, H, w.ln_eps));
+            { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_ln_merge(st, dt, (char*)x + (size_t)row * H * es, (char*)out_tokens + (size_t)orow * H * es,
+                                     w.post_ln_g, w.post_ln_b, (int)(n / grp), grp, H, w.ln_eps)); }
             row += n;
             orow += n / grp;
         }
@@ -379,11 +426,12 @@ cogs_status cogs_project(cogs_handle h, cogs_stream stream, const void* tokens, 
     CogsGemm g; g.dtype = w.dtype;
     g.A = tokens; g.lda = w.in_dim; g.W = w.w1; g.ldw = w.in_dim; g.C = ws; g.ldc = w.out_dim;
     g.bias = w.b1; g.M = M; g.N = w.out_dim; g.K = w.in_dim; g.act = COGS_ACT_GELU_ERF;
-    COGS_TRY(cogs_k_gemm(st, g));
+    { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
     CogsGemm g2; g2.dtype = w.dtype;
     g2.A = ws; g2.lda = w.out_dim; g2.W = w.w2; g2.ldw = w.out_dim; g2.C = out; g2.ldc = w.out_dim;
     g2.bias = w.b2; g2.M = M; g2.N = w.out_dim; g2.K = w.out_dim;
-    return cogs_k_gemm(st, g2);
+    { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g2)); }
+    return COGS_OK;
 }
 
 // ---------------------------------------------------------------- Qwen2
@@ -455,17 +503,17 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
     if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
 
     if (hipMemcpyAsync(x, embeds, (size_t)S * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return COGS_E_HIP;
-    COGS_TRY(cogs_k_llm_rope_table(st, rc, rs, nullptr, pos0, S, h->llm_inv_freq, hd / 2));
+    { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_llm_rope_table(st, rc, rs, nullptr, pos0, S, h->llm_inv_freq, hd / 2)); }
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < w.layers; ++l) {
         const cogs_llm_layer& L = h->llm_layers[l];
-        COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.in_ln, S, H, w.rms_eps));
+        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.in_ln, S, H, w.rms_eps)); }
         {
             CogsGemm g; g.dtype = dt;
             g.A = ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = qd;
             g.bias = L.qkv_b; g.M = S; g.N = qd; g.K = H;
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = qd_q + kvd; g.head_dim = hd;
-            COGS_TRY(cogs_k_gemm(st, g));
+            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         const char* kp = (const char*)qkv + (size_t)qd_q * es;
         const char* vp = kp + (size_t)kvd * es;
@@ -473,8 +521,8 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
         if (kv) {
             char* kc = (char*)kv->k + ((size_t)l * kv->max_len) * kvd * es;
             char* vc = (char*)kv->v + ((size_t)l * kv->max_len) * kvd * es;
-            COGS_TRY(cogs_k_copy_cols(st, dt, kp, qd, kc + (size_t)pos0 * kvd * es, kvd, S, kvd));
-            COGS_TRY(cogs_k_copy_cols(st, dt, vp, qd, vc + (size_t)pos0 * kvd * es, kvd, S, kvd));
+            { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_copy_cols(st, dt, kp, qd, kc + (size_t)pos0 * kvd * es, kvd, S, kvd)); }
+            { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_copy_cols(st, dt, vp, qd, vc + (size_t)pos0 * kvd * es, kvd, S, kvd)); }
             kp = kc; vp = vc; ldkv = kvd;
         }
         {
@@ -486,46 +534,46 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
             if (S == 1 && dt == COGS_DT_BF16 && hd == 128) {
                 a.nsplit = llm_nsplit(ctx); a.ws = split; a.ws_bytes = split_bytes;
             }
-            COGS_TRY(cogs_k_attention(st, a));
+            { PROF(COGS_PROF_ATTN); COGS_TRY(cogs_k_attention(st, a)); }
         }
         {
             CogsGemm g; g.dtype = dt;
             g.A = att; g.lda = qd_q; g.W = L.o_w; g.ldw = qd_q; g.C = x; g.ldc = H;
             g.residual = x; g.ldr = H; g.M = S; g.N = H; g.K = qd_q;
-            COGS_TRY(cogs_k_gemm(st, g));
+            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
-        COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.post_ln, S, H, w.rms_eps));
+        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.post_ln, S, H, w.rms_eps)); }
         {
             CogsGemm g; g.dtype = dt;
             g.A = ln; g.lda = H; g.W = L.gu_w; g.ldw = H; g.C = act; g.ldc = w.inter;
             g.M = S; g.N = 2 * w.inter; g.K = H; g.act = COGS_ACT_SWIGLU;
-            COGS_TRY(cogs_k_gemm(st, g));
+            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         {
             CogsGemm g; g.dtype = dt;
             g.A = act; g.lda = w.inter; g.W = L.down_w; g.ldw = w.inter; g.C = x; g.ldc = H;
             g.residual = x; g.ldr = H; g.M = S; g.N = H; g.K = w.inter;
-            COGS_TRY(cogs_k_gemm(st, g));
+            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
     }
     if (kv) kv->len = ctx;
     const bool need_all = pooled_mean || hidden_out;
     if (need_all) {
         void* hn = hidden_out ? hidden_out : ln;
-        COGS_TRY(cogs_k_rmsnorm(st, dt, x, hn, w.final_norm, S, H, w.rms_eps));
-        if (pooled_mean) COGS_TRY(cogs_k_mean_rows(st, dt, hn, H, S, H, pooled_mean));
+        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, x, hn, w.final_norm, S, H, w.rms_eps)); }
+        if (pooled_mean) { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_mean_rows(st, dt, hn, H, S, H, pooled_mean)); }
         if (last_logits) {
             CogsGemm g; g.dtype = dt;
             g.A = (char*)hn + (size_t)(S - 1) * H * es; g.lda = H; g.W = w.lm_head; g.ldw = H; g.C = last_logits;
             g.ldc = w.vocab; g.M = 1; g.N = w.vocab; g.K = H; g.out_f32 = 1;
-            COGS_TRY(cogs_k_gemm(st, g));
+            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
     } else if (last_logits) {
-        COGS_TRY(cogs_k_rmsnorm(st, dt, (char*)x + (size_t)(S - 1) * H * es, ln, w.final_norm, 1, H, w.rms_eps));
+        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, (char*)x + (size_t)(S - 1) * H * es, ln, w.final_norm, 1, H, w.rms_eps)); }
         CogsGemm g; g.dtype = dt;
         g.A = ln; g.lda = H; g.W = w.lm_head; g.ldw = H; g.C = last_logits; g.ldc = w.vocab;
         g.M = 1; g.N = w.vocab; g.K = H; g.out_f32 = 1;
-        COGS_TRY(cogs_k_gemm(st, g));
+        { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
     }
     return COGS_OK;
 }

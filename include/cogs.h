@@ -59,6 +59,18 @@ const char* cogs_version(void);
 cogs_status cogs_create(int device, cogs_handle* out);
 cogs_status cogs_destroy(cogs_handle h);
 
+/* Optional per-kernel-class timing of the composite calls below (HIP events on `stream`, recorded
+ * around every launch between begin and end). Used by bench.py for the roofline figure; adds a few
+ * microseconds per launch, so it is never on inside a throughput measurement. */
+#define COGS_PROF_GEMM 0
+#define COGS_PROF_ATTN 1
+#define COGS_PROF_NORM 2
+#define COGS_PROF_OTHER 3
+#define COGS_PROF_CLASSES 4
+cogs_status cogs_profile_begin(cogs_handle h);
+/* synchronises `stream`; ms_per_class / launches_per_class: host arrays [COGS_PROF_CLASSES] */
+cogs_status cogs_profile_end(cogs_handle h, cogs_stream stream, float* ms_per_class, int* launches_per_class);
+
 /* ------------------------------------------------------------------ operator level ---- */
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T). nn.Linear / Conv2d(k=s=14) replacement
