@@ -214,7 +214,8 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import vision as ov
         from cogstream_amd.weights import random_vit_state as rvs
-        ncpu = os.cpu_count() or 1
+        # the GPU box gives one GPU a 16-core CPU share; more threads than that only thrash
+        ncpu = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         torch.set_num_threads(ncpu)
         st = rvs(vcfg, seed=0, device="cpu", dtype=torch.float32)
         nfr = 2
