@@ -92,9 +92,10 @@ def main() -> None:
     P = per_frame // 4
     n_patches, m_tokens = T * per_frame, T * P
     pix_all = torch.from_numpy(feats["pixel_values"])
+    from cogstream_amd.parallel import gather_tokens, shard_video
     t_loc = T // world
-    pix = pix_all[rank * t_loc * per_frame:(rank + 1) * t_loc * per_frame].to(dev, torch.bfloat16)  # answer_generate.py:70
-    grid_loc = torch.tensor([[t_loc, gh, gw]])
+    pix_loc, grid_loc = shard_video(pix_all, (T, gh, gw), rank, world)
+    pix = pix_loc.to(dev, torch.bfloat16)  # evaluate/answer_generate.py:70 casts pixel_values to bf16
     merge = torch.tensor([2])
 
     # ---- weights (random, real dimensions) ----
@@ -104,14 +105,9 @@ def main() -> None:
                      dtype=torch.bfloat16, device=dev)
     del vit_state
 
-    gathered = torch.empty(m_tokens, vcfg.hidden_size, device=dev, dtype=torch.bfloat16) if world > 1 else None
-
     def step():
         tok = enc(pix, grid_loc, merge)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, tok)
-            tok = gathered
-        return proj(tok)
+        return proj(gather_tokens(tok, (T, gh, gw), 2, world))
 
     def barrier():
         if world > 1:
@@ -152,7 +148,7 @@ def main() -> None:
         torch.cuda.synchronize()
         L.check(L.lib.cogs_profile_begin(h.h))
         tok = enc(pix, grid_loc, merge)
-        proj(tok if world == 1 else gathered)
+        proj(gather_tokens(tok, (T, gh, gw), 2, world))
         L.check(L.lib.cogs_profile_end(h.h, L.current_stream(), ms, cnt))
         n_loc, m_proj = t_loc * per_frame, (m_tokens if world > 1 else t_loc * P)
         gflops = vit_gemm_flops(n_loc, m_proj, vcfg, lcfg.hidden_size)

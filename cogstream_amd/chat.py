@@ -1,0 +1,354 @@
+"""CogReasoner: host mirror of Videollama3Qwen2ForCausalLM's inference surface
+(model/cogreasoner_chat.py), same method names / argument meaning / return shapes, computing through the
+HIP C ABI:
+
+    qa_selection(...)                         :809-865   Historic Dialogue Retrieval + prompt surgery
+    generate(...) -> (ids [1,n], selection)   :753-807
+    prepare_inputs_labels_for_multimodal      :513-584   encode -> cluster -> compress -> embed
+    encode_images / select_events_based_on_summary / compress_unimportant_events /
+    _get_compression_mask / _compress_visual_tokens / prepare_inputs / generate_language_module
+
+Only control flow, string handling and index bookkeeping live here; every tensor op is a kernel
+(cogstream_amd.ops / vision / llm / kmeans). The object is stateful between qa_selection() and generate()
+exactly like the reference (:812-816)."""
+from __future__ import annotations
+
+import math
+import re
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from .kmeans import kmeans_with_time_min_max, select_additional_frames
+from .llm import Qwen2Engine
+from .qaselect import select_qas
+from .vision import Projector, VisionEncoder
+from .weights import LlmConfig
+
+SUMMARY_INSTRUCTION = (
+    "Concisely list the key points of the event shown in the timestamped images, adhering strictly and honestly to "
+    "the visual content. For each key point, identify relevant objects or actions, note any visible text, and specify "
+    "the approximate timestamp(s). Provide an overview focusing on these key timestamped points.")
+SUMMARY_SYSTEM = "You are a helpful assistant specializing in summarizing events from timestamped visual data."
+
+# model/generation_config.json:2-12
+DEFAULT_GENERATION = dict(do_sample=True, temperature=0.7, top_k=20, top_p=0.8, repetition_penalty=1.05,
+                          eos_token_id=[151645, 151643], pad_token_id=151643)
+
+FRAMES_PER_EVENT = 15      # :280
+MIN_EVENTS = 9             # :281  (k-means only when ceil(T/15) > 9)
+EXTRA_FRAMES = 2           # :284
+COSINE_THRESHOLD = 0.45    # :329
+
+
+def create_visual_summary_prompt(P: int, timestamps, image_token: str = "<image>") -> str:
+    """:93-119 -- P = total visual tokens of the event, one 'Time x.xs:' + P//T placeholders per frame"""
+    T = len(timestamps)
+    per = image_token * (P // T)
+    frames = []
+    for t in range(T):
+        v = timestamps[t].item() if isinstance(timestamps[t], torch.Tensor) else float(timestamps[t])
+        frames.append(f"Time {v:.1f}s:{per}" + ("," if t < T - 1 else ""))
+    return (f"<|im_start|>system\n{SUMMARY_SYSTEM}<|im_end|>\n<|im_start|>user\n" + "".join(frames) + "\n"
+            + SUMMARY_INSTRUCTION + "<|im_end|>\n<|im_start|>assistant")
+
+
+_TIME_RUN_COMMA = re.compile(r"Time \d+\.\d+s:(?:<image>)*,")
+_TIME_RUN_NL = re.compile(r"Time \d+\.\d+s:(?:<image>)*\n")
+_VISUAL_PREFIX = re.compile(r"((?:(?:Time \d+\.\d+s:(?:<image>)*),?)*)\s*(.*)")
+
+
+def process_input_ids(text: str, if_visual: bool, hist_qs: Sequence[str], hist_as: Sequence[str],
+                      current_question: str, tokenizer=None) -> str:
+    """:121-177 -- keep the system turn, the current question, and only the selected history turns; when
+    the selector said 'no', strip every 'Time x.xs:<image>...' run first; a dropped question's visual
+    content is kept and glued to the next kept turn (appendix A quirk)."""
+    if not if_visual:
+        text = _TIME_RUN_COMMA.sub("", text)
+        text = _TIME_RUN_NL.sub("", text)
+    kept: List[str] = []
+    for seg in text.split("<|im_start|>")[1:]:
+        rc = seg.split("\n", 1)
+        if len(rc) != 2:
+            continue
+        role, content = rc[0].strip(), rc[1].split("<|im_end|>")[0].strip()
+        full = f"<|im_start|>{role}\n{content}<|im_end|>\n"
+        if role == "system":
+            kept.append(full)
+        elif role == "user":
+            visual, question = "", content
+            if if_visual:
+                m = _VISUAL_PREFIX.match(content)
+                if m:
+                    visual, question = m.group(1).rstrip(",").strip(), m.group(2).strip()
+            if question == current_question or question in hist_qs:
+                kept.append(full)
+            elif if_visual and visual:
+                kept.append(f"<|im_start|>{role}\n{visual}")
+        elif role == "assistant":
+            if content in hist_as:
+                kept.append(full)
+    kept.append("<|im_start|>assistant\n")
+    out: List[str] = []
+    for i, seg in enumerate(kept):
+        head = "<|im_start|>user\n"
+        if seg.startswith(head) and (i == 0 or not kept[i - 1].rstrip().endswith("<|im_end|>")):
+            body = seg[len(head):]
+            if body.strip():
+                out.append(body)
+            continue
+        out.append(seg)
+    return "".join(out)
+
+
+def parse_selection(selection_module_output: str):
+    """:479-499 -> (if_visual, [indices])"""
+    if_visual = True
+    parts = selection_module_output.strip("[]").split(",")
+    if parts and parts[0]:
+        first = parts[0].strip()
+        if first == "no":
+            if_visual = False
+            parts = parts[1:]
+        elif first == "yes":
+            parts = parts[1:]
+    idx = []
+    for p in parts:
+        p = p.strip()
+        if p:
+            try:
+                idx.append(int(p))
+            except ValueError:
+                continue
+    return if_visual, idx
+
+
+class CogReasoner:
+    def __init__(self, vision: VisionEncoder, projector: Projector, llm: Qwen2Engine, config: Optional[LlmConfig] = None,
+                 generation_config: Optional[dict] = None, use_token_compression: bool = True):
+        self.vision_encoder, self.mm_projector, self.llm = vision, projector, llm
+        self.config = config or llm.cfg
+        self.device, self.dtype = llm.device, llm.dtype
+        self.generation_config = dict(DEFAULT_GENERATION if generation_config is None else generation_config)
+        self.use_token_compression = use_token_compression
+        self.tokenizer = None
+        self.hist_qs: List[str] = []
+        self.hist_as: List[str] = []
+        self.current_question = ""
+        self.all_timestamps: Optional[torch.Tensor] = None
+        self.last_debug: Dict[str, object] = {}
+        self.cosine_override: Optional[Sequence[float]] = None
+
+    # ------------------------------------------------------------------ vision
+    def encode_images(self, pixel_values, grid_sizes, merge_sizes) -> torch.Tensor:
+        """:264-276"""
+        return self.mm_projector(self.vision_encoder(pixel_values, grid_sizes, merge_sizes))
+
+    def _bf16_round(self, x: torch.Tensor) -> torch.Tensor:
+        return x.to(torch.bfloat16).to(torch.float32) if self.dtype == torch.bfloat16 else x
+
+    def _pooled_forward(self, idx: torch.Tensor, mm_features: Optional[torch.Tensor]) -> torch.Tensor:
+        emb = ops.gather_rows(self.llm.packed.embed, mm_features, idx.to(self.device))
+        pooled = self.llm.forward(emb, None, want_logits=False, want_pooled=True)["pooled"]
+        return self._bf16_round(pooled)  # torch.mean of a bf16 tensor is bf16
+
+    def select_events_based_on_summary(self, mm_features: torch.Tensor, total_image_num: int, timestamps) -> List[int]:
+        """:278-333 -- returns the (ascending) frame indices of events that are irrelevant to the question,
+        minus the 2 frames nearest each event centroid"""
+        T = total_image_num
+        P, D = mm_features.shape[0] // T, mm_features.shape[1]
+        K = math.ceil(T / FRAMES_PER_EVENT)
+        if K <= MIN_EVENTS:
+            return []
+        features = mm_features.view(T, P, D)
+        centres, _, assign = kmeans_with_time_min_max(features, timestamps, K)
+        picked = select_additional_frames(features, centres, assign, EXTRA_FRAMES)
+        picked_set = set(torch.cat(picked, dim=0).view(-1).tolist())
+        assign_h = assign.cpu().tolist()
+        ts = timestamps.cpu() if isinstance(timestamps, torch.Tensor) else torch.tensor(timestamps)
+        image_id = self.config.image_token_index
+        pooled = []
+        for k in range(K):
+            frames = [i for i in range(T) if assign_h[i] == k]
+            prompt = create_visual_summary_prompt(len(frames) * P, [ts[i] for i in frames])
+            ids = self.tokenizer(prompt, return_tensors="pt")["input_ids"].reshape(-1).to(torch.int64)
+            rows = torch.tensor([f * P + p for f in frames for p in range(P)], dtype=torch.int64)
+            sel = ids == image_id
+            assert int(sel.sum()) == rows.numel()
+            idx = ids.clone()
+            idx[sel] = -(rows + 1)
+            pooled.append(self._pooled_forward(idx, mm_features))
+        q = self.tokenizer(self.current_question, padding=True, truncation=True, return_tensors="pt", max_length=128)
+        qvec = self._pooled_forward(q["input_ids"].reshape(-1).to(torch.int64), None)
+        cos = self._bf16_round(ops.cosine(qvec, torch.stack(pooled).contiguous())).cpu()
+        assert cos.shape[0] == K
+        self.last_debug.update(cosine_raw=cos.clone())
+        if self.cosine_override is not None:  # test hook: pin the branch below with forced similarities
+            cos = torch.tensor(self.cosine_override, dtype=torch.float32)
+        thr =float(torch.tensor(COSINE_THRESHOLD).to(self.dtype)) if self.dtype == torch.bfloat16 else COSINE_THRESHOLD
+        minor_clusters = set(torch.where(cos < thr)[0].tolist())
+        self.last_debug.update(assign=assign_h, cosine=cos, picked=sorted(picked_set))
+        return [i for i in range(T) if assign_h[i] in minor_clusters and i not in picked_set]
+
+    def compress_unimportant_events(self, mm_features: torch.Tensor, patch_num: int, minor_frame_indices: List[int]):
+        """:434-447 (returns a copy, like the reference's .clone())"""
+        total = mm_features.shape[0]
+        if total % patch_num != 0:
+            raise ValueError(f"total patches ({total}) not divisible by patches per frame ({patch_num})")
+        out = mm_features.clone()
+        if minor_frame_indices:
+            ops.frame_mean_to_slot0(out, patch_num, torch.tensor(minor_frame_indices, dtype=torch.int32, device=out.device))
+        return out
+
+    def _get_compression_mask(self, pixel_values, batched_num_patches, grid_sizes, merge_sizes, modals,
+                              threshold: float = 0.1, min_tokens: int = 1,
+                              minor_frame_indices: Optional[List[int]] = None) -> torch.Tensor:
+        """:383-432 -> bool [M] on the device"""
+        minor = set(minor_frame_indices or [])
+        masks = []
+        row = 0
+        gcount = 0
+        for n, gs, ms, modal in zip(batched_num_patches.tolist(), grid_sizes.tolist(), merge_sizes.tolist(), modals):
+            t, h, w = gs
+            npatch = t * h * w
+            if modal == "image" or (modal == "video" and t == 1):
+                masks.append(torch.ones(n, dtype=torch.uint8, device=pixel_values.device))
+            elif modal == "video":
+                flags = torch.tensor([1 if gcount + f in minor else 0 for f in range(t)], dtype=torch.uint8,
+                                     device=pixel_values.device)
+                masks.append(ops.pixdiff_mask(pixel_values[row:row + npatch], t, (h // ms) * (w // ms), threshold,
+                                              min_tokens, flags))
+            else:
+                masks.append(torch.ones(0, dtype=torch.uint8, device=pixel_values.device))
+            row += npatch
+            gcount += t
+        return torch.cat(masks).bool()
+
+    def _compress_visual_tokens(self, compression_mask, input_ids, attention_mask):
+        """:449-476 (inference subset). Returns (row index of every kept visual token, input_ids', mask')"""
+        keep = compression_mask.cpu().numpy().astype(bool)
+        ids = input_ids.cpu().numpy()
+        sel = ids == self.config.image_token_index
+        text_mask = ~sel
+        text_mask[sel] = keep
+        new_ids = torch.from_numpy(ids[text_mask])
+        new_mask = attention_mask.cpu()[torch.from_numpy(text_mask)] if attention_mask is not None else None
+        return torch.from_numpy(np.nonzero(keep)[0]), new_ids, new_mask
+
+    # ------------------------------------------------------------------ multimodal assembly
+    def prepare_inputs_labels_for_multimodal(self, input_ids=None, attention_mask=None, pixel_values=None,
+                                             grid_sizes=None, merge_sizes=None, modals=None, total_image_num=0,
+                                             if_visual=True):
+        """:513-584 -> (inputs_embeds [1,S',H] on the device, attention_mask [1,S'])"""
+        B, N = input_ids.shape
+        assert B == 1, "Token compression is only supported for batch_size=1"
+        ids = input_ids.reshape(-1).cpu()
+        am = attention_mask.reshape(-1) if attention_mask is not None else None
+        mm = None
+        if if_visual:
+            pixel_values = pixel_values.to(self.device)
+            batched = grid_sizes.prod(dim=1).div(merge_sizes ** 2).long()
+            mm = self.encode_images(pixel_values, grid_sizes, merge_sizes)
+            text_rows = [m == "text" for m in modals]
+            if any(text_rows):  # _get_valid_visual_tokens (:336-347)
+                keep = torch.cat([torch.full((int(n),), not tr, dtype=torch.bool) for n, tr in zip(batched, text_rows)])
+                mm = mm[keep.to(mm.device)].contiguous()
+            assert mm.shape[0] % total_image_num == 0, f"{mm.shape[0]} % {total_image_num} != 0"
+            frame_indices = self.select_events_based_on_summary(mm, total_image_num, self.all_timestamps)
+            mm = self.compress_unimportant_events(mm, mm.shape[0] // total_image_num, frame_indices)
+            mask = self._get_compression_mask(pixel_values, batched, grid_sizes, merge_sizes, modals,
+                                              minor_frame_indices=frame_indices)
+            self.last_debug.update(minor_frames=frame_indices, compression_mask=mask)
+            if self.use_token_compression:
+                rows, ids, am = self._compress_visual_tokens(mask, ids, am)
+            else:
+                rows = torch.arange(mm.shape[0])
+            idx = ids.clone().to(torch.int64)
+            sel = idx == self.config.image_token_index
+            assert int(sel.sum()) == rows.numel(), (int(sel.sum()), rows.numel())
+            idx[sel] = -(rows.to(torch.int64) + 1)
+        else:
+            idx = ids.to(torch.int64)
+        embeds = ops.gather_rows(self.llm.packed.embed, mm, idx.to(self.device))
+        self.last_debug.update(input_ids=ids)
+        return embeds.unsqueeze(0), (am.reshape(1, -1) if am is not None else None)
+
+    # ------------------------------------------------------------------ text side
+    def prepare_inputs(self, selection_module_output: str, original_text: Optional[str] = None):
+        """:478-511 (inference branch) -> (tokenized new prompt, if_visual)"""
+        if_visual, sel = parse_selection(selection_module_output)
+        hist_qs = [self.hist_qs[i] for i in sel if i < len(self.hist_qs)]
+        hist_as = [self.hist_as[i] for i in sel if i < len(self.hist_qs)]  # sic: bound by len(hist_qs) (:502)
+        prompt = process_input_ids(original_text, if_visual, hist_qs, hist_as, self.current_question, self.tokenizer)
+        return self.tokenizer(prompt, padding=False, return_tensors="pt"), if_visual
+
+    def generate_language_module(self, input_ids=None, attention_mask=None, max_new_tokens: int = 50,
+                                 do_sample: bool = False, allowed_ids: Optional[Sequence[int]] = None,
+                                 eos_token_id=151645, **kw) -> torch.Tensor:
+        """:877-908 -- greedy decode from token ids; returns prompt + new ids [1, S+n] (ids were passed, so HF
+        returns the prompt too and the repetition penalty sees the prompt ids)"""
+        ids = input_ids.reshape(-1).to(torch.int64)
+        emb = self.llm.embed_tokens(ids)
+        eos = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
+        new = self.llm.generate(emb, max_new_tokens=max_new_tokens, eos_token_id=eos, do_sample=do_sample,
+                                repetition_penalty=self.generation_config.get("repetition_penalty", 1.0),
+                                allowed_ids=allowed_ids, prompt_ids=ids)
+        return torch.cat([ids, torch.tensor(new, dtype=torch.int64)]).unsqueeze(0)
+
+    def qa_selection(self, current_question=None, hist_qs=None, hist_as=None, tokenizer=None, original_text=None,
+                     input_ids=None, attention_mask=None, mode="FCC", select_gt=None, if_visual=None, **kwargs):
+        """:809-865"""
+        self.tokenizer, self.hist_qs, self.hist_as = tokenizer, hist_qs, hist_as
+        self.current_question = current_question
+        self.all_timestamps = torch.tensor(kwargs.pop("all_timestamps", None))
+        new_ids, new_mask, out_str, vis = input_ids, attention_mask, "", True
+        if mode == "FCC":
+            if len(hist_qs) > 0:
+                out_str = select_qas(current_question, hist_qs, hist_as, self, tokenizer)
+        elif mode == "AC":
+            pass
+        elif mode == "NC":
+            if len(hist_qs) > 0:
+                out_str = "[yes]"
+        elif mode == "gt":
+            assert select_gt is not None, "in gt mode, you should provide selection gt"
+            if len(hist_qs) > 0:
+                out_str = "[" + ",".join(["yes" if if_visual else "no"] + [str(n) for n in select_gt]) + "]"
+        else:
+            raise ValueError(f"unknown mode {mode}")
+        if out_str:
+            new_inputs, vis = self.prepare_inputs(out_str, original_text=original_text)
+            new_ids, new_mask = new_inputs["input_ids"], new_inputs["attention_mask"]
+        return {"new_input_ids": new_ids, "new_attention_mask": new_mask, "selection_module_output": out_str,
+                "input_ids": input_ids, "attention_mask": attention_mask, "if_visual": vis, **kwargs}
+
+    @torch.no_grad()
+    def generate(self, pixel_values=None, grid_sizes=None, merge_sizes=None, modals=None, new_input_ids=None,
+                 new_attention_mask=None, selection_module_output="", if_visual=True, **kwargs):
+        """:753-807 -> (new token ids [1, n], selection_module_output)"""
+        for k in ("input_ids", "past_key_values", "attention_mask", "position_ids", "tokenizer", "hist_qs", "hist_as",
+                  "current_question", "original_text"):
+            kwargs.pop(k, None)
+        total_image_num = kwargs.pop("total_image_num", None)
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")
+        if pixel_values is not None:
+            embeds, _ = self.prepare_inputs_labels_for_multimodal(
+                input_ids=new_input_ids, attention_mask=new_attention_mask, pixel_values=pixel_values,
+                grid_sizes=grid_sizes, merge_sizes=merge_sizes, modals=modals, total_image_num=total_image_num,
+                if_visual=if_visual)
+            embeds = embeds[0]
+        else:
+            embeds = self.llm.embed_tokens(new_input_ids.reshape(-1))
+        g = dict(self.generation_config)
+        g.update({k: v for k, v in kwargs.items() if k in ("do_sample", "temperature", "top_k", "top_p",
+                                                            "repetition_penalty", "eos_token_id", "generator")})
+        eos = g.get("eos_token_id", [])
+        eos = [eos] if isinstance(eos, int) else list(eos)
+        new = self.llm.generate(embeds, max_new_tokens=int(kwargs.get("max_new_tokens", 1024)), eos_token_id=eos,
+                                do_sample=bool(g.get("do_sample", False)), temperature=float(g.get("temperature", 1.0)),
+                                top_k=int(g.get("top_k", 0) or 0), top_p=float(g.get("top_p", 1.0)),
+                                repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"))
+        return torch.tensor(new, dtype=torch.int64).unsqueeze(0), selection_module_output

@@ -1,0 +1,92 @@
+"""Time-aware k-means with the reference's call surface, device steps through the C ABI.
+
+    kmeans_with_time_min_max(features, timestamp, cluster_num, alpha=2, max_iteration=30, tol=1e-4)
+        -> (centres [K,P,D] fp32, centre_times [K], assignments [T] int64)     model/kmeans_with_time.py:4-137
+    select_additional_frames(cls_feature, long_memory, cluster_assignments, n)  model/cogreasoner_chat.py:50-64
+
+The random draws stay on the host exactly where the reference makes them (python `random` for the first
+centre and for empty-cluster reseeds, torch.multinomial on the CPU generator for k-means++), so that under
+the same seeds the same indices are drawn; the feature arithmetic (distances, assignments, means, centre
+shift) runs in HIP kernels over the features resident in HBM (bf16 or fp32, never copied to the host)."""
+from __future__ import annotations
+
+import random
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int, alpha: float = 2,
+                             max_iteration: int = 30, tol: float = 1e-4
+                             ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    if not isinstance(timestamp, torch.Tensor):
+        timestamp = torch.tensor(timestamp, dtype=torch.float32)
+    T, P, D = features.shape
+    if T <= cluster_num:  # kmeans_with_time.py:30-32
+        return features.to(torch.float32), timestamp[:cluster_num], None
+    dev = features.device
+    x = features.reshape(T, P * D).contiguous()
+    ts = timestamp.to(dev, torch.float32).contiguous()
+    K, PD = cluster_num, P * D
+    ws = ops.kmeans_workspace(T, PD, K, dev)
+
+    # ---- k-means++ on feature distance only (:41-62) ----
+    idx: List[int] = [random.randint(0, T - 1)]
+    nearest2 = None
+    while len(idx) < K:
+        row = torch.tensor([idx[-1]], dtype=torch.int32, device=dev)
+        d2 = ops.kmeans_sqdist(x, None, row, 1, ws)[:, 0]          # distance^2 to the newest centre
+        nearest2 = d2 if nearest2 is None else torch.minimum(nearest2, d2)
+        probs = nearest2.cpu()                                       # (sqrt(d2))**2 of the reference
+        s = probs.sum()
+        if s.item() == 0:
+            new = random.randint(0, T - 1)
+        else:
+            new = int(torch.multinomial(probs / s, 1).item())        # CPU generator, like the reference
+        idx.append(new)
+
+    rows = torch.tensor(idx, dtype=torch.int64, device=dev)
+    centres = ops.pack_rows(x.index_select(0, rows), torch.float32, PD) if x.dtype != torch.float32 \
+        else x.index_select(0, rows).contiguous()
+    centre_ts = ts.index_select(0, rows).contiguous()
+    assign = None
+    zeros = torch.zeros(K, dtype=torch.int32, device=dev)
+    for _ in range(max_iteration):
+        d2 = ops.kmeans_sqdist(x, centres, None, K, ws)
+        assign, counts = ops.kmeans_assign(d2, ts, centre_ts, float(alpha))
+        empty = (counts.cpu() == 0).nonzero().flatten().tolist()
+        if empty:
+            reseed = [0] * K
+            for k in empty:                                          # ascending i, one draw each (:116-120)
+                reseed[k] = random.randint(0, T - 1)
+            reseed_t = torch.tensor(reseed, dtype=torch.int32, device=dev)
+        else:
+            reseed_t = zeros
+        shift = ops.kmeans_update(x, ts, assign, reseed_t, centres, centre_ts, ws)
+        if float(shift) <= tol:
+            break
+    return centres.view(K, P, D), centre_ts, assign
+
+
+def select_additional_frames(cls_feature: torch.Tensor, long_memory: torch.Tensor,
+                             cluster_assignments: torch.Tensor, additional_frame_num: int) -> List[torch.Tensor]:
+    """per cluster: all members if <= n, else the n members nearest (L2 over P*D) to the centroid"""
+    T = cls_feature.shape[0]
+    K = long_memory.shape[0]
+    dev = cls_feature.device
+    x = cls_feature.reshape(T, -1).contiguous()
+    c = long_memory.reshape(K, -1).to(torch.float32).contiguous()
+    ws = ops.kmeans_workspace(T, x.shape[1], K, dev)
+    d2 = ops.kmeans_sqdist(x, c, None, K, ws).cpu()
+    assign = cluster_assignments.cpu()
+    out = []
+    for i in range(K):
+        members = torch.nonzero(assign == i, as_tuple=True)[0]
+        if members.numel() <= additional_frame_num:
+            out.append(members.to(dev))
+        else:
+            _, top = torch.topk(d2[members, i], k=additional_frame_num, largest=False)
+            out.append(members[top].to(dev))
+    return out

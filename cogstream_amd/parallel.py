@@ -1,0 +1,51 @@
+"""Frame sharding of the encoder over the GPUs of one node (build-only, the reference
+never shards a clip). Legal because block-diagonal attention, RoPE and the 2x2 merge are all per frame
+(model/modeling_videollama3_encoder.py:309-312,427,487-501): rank r encodes a contiguous slice of frames,
+one all-gather (RCCL over xGMI on the GPU, gloo in the CPU tests) reassembles the [M,1152] visual tokens in
+frame order. One process per GPU; no other data-path collective."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def frame_shards(num_frames: int, world: int) -> List[Tuple[int, int]]:
+    """contiguous [begin, end) frame ranges, sizes differing by at most one"""
+    base, rem = divmod(num_frames, world)
+    out, b = [], 0
+    for r in range(world):
+        e = b + base + (1 if r < rem else 0)
+        out.append((b, e))
+        b = e
+    return out
+
+
+def shard_video(pixel_values: torch.Tensor, grid_size: Tuple[int, int, int], rank: int, world: int):
+    """rows of this rank's frames of ONE video + its local grid"""
+    t, gh, gw = (int(v) for v in grid_size)
+    b, e = frame_shards(t, world)[rank]
+    per = gh * gw
+    return pixel_values[b * per:e * per], torch.tensor([[e - b, gh, gw]])
+
+
+def gather_tokens(local_tokens: torch.Tensor, grid_size: Tuple[int, int, int], merge_size: int, world: int,
+                  group=None) -> torch.Tensor:
+    """all-gather the per-rank merged tokens back into frame order -> [M, hidden] on every rank"""
+    if world == 1:
+        return local_tokens
+    t, gh, gw = (int(v) for v in grid_size)
+    ppf = (gh // merge_size) * (gw // merge_size)
+    shards = frame_shards(t, world)
+    if all(e - b == shards[0][1] - shards[0][0] for b, e in shards):
+        out = torch.empty(t * ppf, local_tokens.shape[1], dtype=local_tokens.dtype, device=local_tokens.device)
+        dist.all_gather_into_tensor(out, local_tokens.contiguous(), group=group)
+        return out
+    # ragged split: collectives need equal counts, so pad every shard to the largest one and trim after
+    rows = max(e - b for b, e in shards) * ppf
+    padded = local_tokens.new_zeros(rows, local_tokens.shape[1])
+    padded[: local_tokens.shape[0]] = local_tokens
+    out = torch.empty(world * rows, local_tokens.shape[1], dtype=local_tokens.dtype, device=local_tokens.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * rows: r * rows + (e - b) * ppf] for r, (b, e) in enumerate(shards)], dim=0)

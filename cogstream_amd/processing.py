@@ -164,22 +164,18 @@ def expand_image_tokens(text: str, tokens_per_image: Sequence[int]) -> str:
 
 def process_history_qas(conversation: List[Dict[str, Any]]) -> Tuple[List[str], List[str], str]:
     """processing_cogreasoner.py:936-956: past (question, answer) strings and the current question"""
-    def text_of(msg):
-        c = msg["content"]
-        if isinstance(c, str):
-            return c
-        return "".join(x if isinstance(x, str) else x.get("text", "") for x in c if isinstance(x, str) or "text" in x)
-
-    qs, ans = [], []
-    pending = None
+    qs: List[str] = []
+    ans: List[Any] = []
     for msg in conversation:
-        if msg["role"] == "user":
-            pending = text_of(msg)
-        elif msg["role"] == "assistant" and pending is not None:
-            qs.append(pending)
-            ans.append(text_of(msg))
-            pending = None
-    return qs, ans, (pending or "")
+        role, content = msg.get("role"), msg.get("content")
+        if role == "user":
+            if isinstance(content, str):
+                qs.append(content)
+            elif isinstance(content, list):
+                qs.extend(c.get("text") for c in content if isinstance(c, dict) and c.get("type") == "text")
+        elif role == "assistant":
+            ans.append(content)
+    return qs[:-1], ans, (qs[-1] if qs else "")
 
 
 class CogStreamProcessor:

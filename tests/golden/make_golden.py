@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE (imported from
+/root/reference, CPU, fp32, eager) on small seeded inputs. Runs only in the build container -- the
+reference does not exist on the GPU box; the fixtures (inputs + expected outputs, data only) are committed.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Weights are not stored: both sides regenerate them with cogstream_amd.weights.random_*_state(seed) (torch CPU
+generator, same image on both boxes); each fixture stores a weight checksum so RNG drift is detected."""
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from model import cogreasoner_chat as ref_chat  # noqa: E402
+from model.configuration_videollama3 import Videollama3Qwen2Config  # noqa: E402
+from model.configuration_videollama3_encoder import Videollama3VisionEncoderConfig  # noqa: E402
+from model.kmeans_with_time import kmeans_with_time_min_max as ref_kmeans  # noqa: E402
+from model.modeling_videollama3_encoder import Videollama3VisionEncoderModel  # noqa: E402
+from model.qaselect_module_predict import format_example as ref_format_example  # noqa: E402
+
+from cogstream_amd.weights import (LlmConfig, VisionConfig, random_llm_state, random_proj_state,  # noqa: E402
+                                   random_vit_state)
+from toy_tokenizer import IM_END, IMAGE, VOCAB, ToyTokenizer  # noqa: E402
+from golden.inputs import FORCED_COSINE, e2e_inputs  # noqa: E402
+
+VIT = dict(hidden_size=576, intermediate_size=200, num_hidden_layers=2, num_attention_heads=8)
+LLM = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+           num_key_value_heads=1, vocab_size=VOCAB, image_token_index=IMAGE, eos_token_id=IM_END)
+
+
+def checksum(state):
+    return float(sum(v.double().abs().sum() for v in state.values()))
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+def ref_vit(state, cfg):
+    c = Videollama3VisionEncoderConfig(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                                       num_hidden_layers=cfg.num_hidden_layers,
+                                       num_attention_heads=cfg.num_attention_heads, patch_size=14)
+    c._attn_implementation = "eager"
+    m = Videollama3VisionEncoderModel(c).eval()
+    missing = m.load_state_dict(state, strict=True)
+    return m
+
+
+def golden_vit():
+    cfg = VisionConfig(**VIT)
+    st = random_vit_state(cfg, seed=3, std=0.05)
+    m = ref_vit(st, cfg)
+    g = torch.Generator().manual_seed(21)
+    grid = torch.tensor([[3, 4, 6], [2, 2, 4]])
+    merge = torch.tensor([2, 2])
+    n = int(grid.prod(1).sum())
+    pix = torch.rand(n, 588, generator=g) * 2 - 1
+    with torch.no_grad():
+        eager_global = m(pix, grid, merge)                     # reference CPU path: global attention + 1.0 bias
+        # block-diagonal (= the flash path the reference ships with): one frame per call
+        outs, row = [], 0
+        for (t, h, w), ms in zip(grid.tolist(), merge.tolist()):
+            for f in range(t):
+                outs.append(m(pix[row:row + h * w], torch.tensor([[1, h, w]]), torch.tensor([ms])))
+                row += h * w
+        block_diag = torch.cat(outs, 0)
+    pst = random_proj_state(cfg.hidden_size, LLM["hidden_size"], seed=1, std=0.05)
+    cfg_ns = types.SimpleNamespace(vision_encoder_config=types.SimpleNamespace(hidden_size=cfg.hidden_size),
+                                   hidden_size=LLM["hidden_size"])
+    proj = ref_chat.MlpGeluProjector(cfg_ns, "mlp2x_gelu").eval()
+    proj.load_state_dict(pst, strict=True)
+    with torch.no_grad():
+        projected = proj(block_diag)
+    save("vit_tiny.npz", pixel_values=pix, grid_sizes=grid, merge_sizes=merge, eager_global=eager_global,
+         block_diag=block_diag, projected=projected, vit_checksum=np.float64(checksum(st)),
+         proj_checksum=np.float64(checksum(pst)))
+
+
+def golden_kmeans():
+    cases = {}
+    for ci, (T, P, D, K, seed) in enumerate([(150, 3, 16, 10, 0), (64, 2, 8, 5, 1), (40, 1, 32, 6, 2), (6, 2, 4, 8, 3)]):
+        g = torch.Generator().manual_seed(100 + ci)
+        centers = torch.randn(K, P * D, generator=g) * 4
+        lab = torch.randint(0, K, (T,), generator=g)
+        feats = (centers[lab] + 0.5 * torch.randn(T, P * D, generator=g)).view(T, P, D)
+        if ci == 2:
+            feats = feats.bfloat16()                          # the GPU path hands bf16 features over
+        ts = torch.arange(T, dtype=torch.float32) + 0.5 * torch.rand(T, generator=g)
+        random.seed(seed)
+        torch.manual_seed(seed)
+        cf, ct, assign = ref_kmeans(feats, ts, K)
+        cases[f"c{ci}_features"] = feats.float()
+        cases[f"c{ci}_is_bf16"] = np.int64(ci == 2)
+        cases[f"c{ci}_ts"] = ts
+        cases[f"c{ci}_K"] = np.int64(K)
+        cases[f"c{ci}_seed"] = np.int64(seed)
+        cases[f"c{ci}_centres"] = cf.float()
+        cases[f"c{ci}_centre_ts"] = ct
+        if assign is not None:
+            cases[f"c{ci}_assign"] = assign
+            sel = ref_chat.select_additional_frames(feats, cf, assign, 2)
+            cases[f"c{ci}_extra"] = torch.cat(sel).sort().values
+            cases[f"c{ci}_extra_counts"] = torch.tensor([len(s) for s in sel])
+    cases["n_cases"] = np.int64(4)
+    save("kmeans.npz", **cases)
+
+
+def golden_compress():
+    g = torch.Generator().manual_seed(31)
+    t, gh, gw, ms = 6, 4, 6, 2
+    P, E = (gh // ms) * (gw // ms), ms * ms * 588
+    base = torch.rand(1, P, E, generator=g) * 2 - 1
+    pix = base.repeat(t, 1, 1)
+    pix[1] += 0.002 * torch.randn(P, E, generator=g)
+    pix[2, :3] += 0.5 * torch.randn(3, E, generator=g)
+    pix[4] = pix[3]
+    pix = pix.reshape(-1, 588)
+    grid, merge = torch.tensor([[t, gh, gw]]), torch.tensor([ms])
+    batched = grid.prod(dim=1).div(merge ** 2).long()
+    fn = ref_chat.Videollama3MetaForCausalLM._get_compression_mask
+    out = {}
+    for tag, px in (("f32", pix), ("bf16", pix.bfloat16())):
+        out[f"mask_{tag}"] = fn(None, px, batched, grid, merge, ["video"], minor_frame_indices=[])
+        out[f"mask_minor_{tag}"] = fn(None, px, batched, grid, merge, ["video"], minor_frame_indices=[2, 5])
+    mm = torch.randn(t * P, 64, generator=g)
+    ev = ref_chat.Videollama3MetaForCausalLM.compress_unimportant_events(None, mm, P, [1, 4])
+    ids = torch.tensor([1, 2] + sum(([70, 71] + [IMAGE] * P + [44] for _ in range(t)), []) + [9, 9, 9])
+    self_ns = types.SimpleNamespace(config=types.SimpleNamespace(image_token_index=IMAGE))
+    mask = out["mask_minor_f32"]
+    mm2, ids2, am2, _, _ = ref_chat.Videollama3MetaForCausalLM._compress_visual_tokens(
+        self_ns, mask, ev, ids, torch.ones_like(ids))
+    save("compress.npz", pixel_values=pix, grid_sizes=grid, merge_sizes=merge, mm=mm, event_pooled=ev,
+         input_ids=ids, ids_compressed=ids2, mm_compressed=mm2, **out)
+
+
+def golden_text():
+    tok = ToyTokenizer()
+    img = "<image>" * 2
+    sys_ = "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n"
+    text = (sys_ + f"<|im_start|>user\nTime 0.0s:{img},Time 1.0s:{img}\nWhat is on the table?<|im_end|>\n"
+            "<|im_start|>assistant\nA red cup.<|im_end|>\n"
+            f"<|im_start|>user\nTime 2.0s:{img},Time 3.5s:{img}\nWho enters the room?<|im_end|>\n"
+            "<|im_start|>assistant\nA man in a blue coat.<|im_end|>\n"
+            f"<|im_start|>user\nTime 4.0s:{img}\nWhat does he pick up?<|im_end|>\n<|im_start|>assistant\n")
+    hq = ["What is on the table?", "Who enters the room?"]
+    ha = ["A red cup.", "A man in a blue coat."]
+    cur = "What does he pick up?"
+    cases = []
+    for sel in ["[yes,0,1]", "[yes,1]", "[yes]", "[no,0]", "[no]", "[yes,0]", "[no,0,1]", "[yes,5]", "[maybe,1]"]:
+        ns = types.SimpleNamespace(hist_qs=hq, hist_as=ha, current_question=cur, tokenizer=tok)
+        new_inputs, if_visual = ref_chat.Videollama3MetaForCausalLM.prepare_inputs(ns, sel, original_text=text)
+        cases.append({"selection": sel, "if_visual": bool(if_visual),
+                      "prompt": tok.decode(new_inputs["input_ids"][0]), "ids": new_inputs["input_ids"][0].tolist()})
+    summary = ref_chat.create_visual_summary_prompt(6, torch.tensor([0.0, 1.04, 12.5]))
+    qa_prompt = ref_format_example({"current_Q": cur, "hist_Qs": hq, "hist_As": ha})
+    qa_prompt_nodemo = ref_format_example({"current_Q": cur, "hist_Qs": hq, "hist_As": ha}, include_demo=False)
+    with open(os.path.join(HERE, "text.json"), "w") as f:
+        json.dump({"original_text": text, "hist_qs": hq, "hist_as": ha, "current_question": cur, "cases": cases,
+                   "summary_prompt": summary, "qa_prompt": qa_prompt, "qa_prompt_nodemo": qa_prompt_nodemo}, f, indent=1)
+    print("wrote text.json")
+
+
+def build_ref_model(vst, pst, lst):
+    vcfg = dict(VIT, patch_size=14)
+    cfg = Videollama3Qwen2Config(vision_encoder_config=vcfg, image_token_index=IMAGE, vocab_size=VOCAB,
+                                 hidden_size=LLM["hidden_size"], intermediate_size=LLM["intermediate_size"],
+                                 num_hidden_layers=LLM["num_hidden_layers"], num_attention_heads=LLM["num_attention_heads"],
+                                 num_key_value_heads=LLM["num_key_value_heads"], rms_norm_eps=1e-6, rope_theta=1e6,
+                                 max_position_embeddings=32768, tie_word_embeddings=False, eos_token_id=IM_END,
+                                 bos_token_id=259, pad_token_id=259, use_token_compression=True)
+    cfg._attn_implementation = "eager"
+    cfg.vision_encoder_config._attn_implementation = "eager"
+    model = ref_chat.Videollama3Qwen2ForCausalLM(cfg).eval()
+    sd = {}
+    for k, v in vst.items():
+        sd["model.vision_encoder." + k] = v
+    for k, v in pst.items():
+        sd["model.mm_projector." + k] = v
+    for k, v in lst.items():
+        sd[("lm_head.weight" if k == "lm_head.weight" else "model." + k)] = v
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all("rotary" in k or "inv_freq" in k for k in res.missing_keys), res.missing_keys
+    return model
+
+
+def golden_e2e():
+    """full reference pipeline, tiny model, toy tokenizer, greedy: (a) 8 frames + 2 history turns (retrieval +
+    prompt surgery), (b) 150 frames (k-means, K=10 event passes, event compression). The reference's CPU path is
+    the eager/global-attention encoder."""
+    vst = random_vit_state(VisionConfig(**VIT), seed=3, std=0.05)
+    pst = random_proj_state(VIT["hidden_size"], LLM["hidden_size"], seed=1, std=0.05)
+    lst = random_llm_state(LlmConfig(**LLM), seed=7, std=0.05)
+    model = build_ref_model(vst, pst, lst)
+    tok = ToyTokenizer()
+    out = {"vit_checksum": np.float64(checksum(vst)), "llm_checksum": np.float64(checksum(lst))}
+    for tag, T, hist in (("a", 8, True), ("b", 150, False), ("c", 150, False)):
+        inp = e2e_inputs(tag)
+        pix, grid, merge, ts, text = inp["pixel_values"], inp["grid_sizes"], inp["merge_sizes"], inp["timestamps"], inp["text"]
+        hq, ha, cur = inp["hist_qs"], inp["hist_as"], inp["current_question"]
+        enc = tok(text)
+        random.seed(5)
+        torch.manual_seed(5)
+        with torch.no_grad():
+            sel = model.qa_selection(current_question=cur, hist_qs=hq, hist_as=ha, tokenizer=tok, original_text=text,
+                                     input_ids=enc["input_ids"], attention_mask=enc["attention_mask"], mode="FCC",
+                                     all_timestamps=ts)
+            # instrument: capture the intermediate products of prepare_inputs_labels_for_multimodal
+            cap = {}
+            orig_sel = model.select_events_based_on_summary
+            orig_mask = model._get_compression_mask
+
+            def wrap_sel(mm, n, t_):
+                r = orig_sel(mm, n, t_)
+                cap["minor"] = list(r)
+                cap["mm_features"] = mm.clone()
+                return r
+
+            def wrap_mask(*a, **k):
+                r = orig_mask(*a, **k)
+                cap["mask"] = r.clone()
+                return r
+
+            model.select_events_based_on_summary = wrap_sel
+            model._get_compression_mask = wrap_mask
+            # capture (b) / force (c) the event-vs-question cosines and capture the cluster assignments
+            orig_cos, orig_km = ref_chat.F.cosine_similarity, ref_chat.kmeans_with_time_min_max
+            forced = torch.tensor(FORCED_COSINE)
+
+            def wrap_cos(a, b, dim=1):
+                r = orig_cos(a, b, dim=dim)
+                cap["cosine"] = r.clone()
+                return forced.to(r.dtype) if tag == "c" else r
+
+            def wrap_km(f, t_, k):
+                r = orig_km(f, t_, k)
+                cap["assign"] = r[2].clone()
+                return r
+
+            ref_chat.F.cosine_similarity = wrap_cos
+            ref_chat.kmeans_with_time_min_max = wrap_km
+            new_ids, sel_str = model.generate(pixel_values=pix, grid_sizes=grid, merge_sizes=merge, modals=["video"],
+                                              new_input_ids=sel["new_input_ids"], new_attention_mask=sel["new_attention_mask"],
+                                              selection_module_output=sel["selection_module_output"],
+                                              if_visual=sel["if_visual"], total_image_num=T, max_new_tokens=8,
+                                              do_sample=False, repetition_penalty=1.05)
+            model.select_events_based_on_summary = orig_sel
+            model._get_compression_mask = orig_mask
+            ref_chat.F.cosine_similarity, ref_chat.kmeans_with_time_min_max = orig_cos, orig_km
+        out.update({f"{tag}_pix_checksum": np.float64(pix.double().abs().sum()), f"{tag}_T": np.int64(T),
+                    f"{tag}_selection": np.array(sel["selection_module_output"]),
+                    f"{tag}_if_visual": np.int64(bool(sel["if_visual"])), f"{tag}_new_input_ids": sel["new_input_ids"][0],
+                    f"{tag}_minor": np.array(cap.get("minor", []), dtype=np.int64),
+                    f"{tag}_mask": cap["mask"] if "mask" in cap else np.zeros(0, dtype=bool),
+                    f"{tag}_mm_features": cap.get("mm_features", torch.zeros(0)),
+                    f"{tag}_tokens": new_ids[0], f"{tag}_sel_out": np.array(sel_str),
+                    f"{tag}_cosine": cap.get("cosine", torch.zeros(0)), f"{tag}_assign": cap.get("assign", torch.zeros(0, dtype=torch.long)),
+                    })
+        print(tag, "selection:", repr(sel["selection_module_output"]), "minor frames:", len(cap.get("minor", [])),
+              "kept tokens:", int(cap["mask"].sum()) if "mask" in cap else None, "new tokens:", new_ids[0].tolist())
+    save("e2e.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["vit", "kmeans", "compress", "text", "e2e"]
+    with torch.no_grad():
+        for w in which:
+            globals()["golden_" + w]()

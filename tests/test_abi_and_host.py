@@ -1,0 +1,112 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/cogs.h declares (no compute
+calls without a GPU), the product path refuses to run without a GPU, and the host preprocessing contract."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cogstream_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "cogs.h")).read()
+    declared = set(re.findall(r"\b(cogs_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"cogs_status"}
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(L.lib, name), f"{name} declared in include/cogs.h but not exported"
+        assert name in L.SIGNATURES, f"{name} has no ctypes signature"
+    assert L.lib.cogs_status_string(-4).decode() == "workspace missing or too small"
+    assert b"gfx950" in L.lib.cogs_version()
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must be rejected loudly, never computed on the host"""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cogstream_amd import _lib as L
+    from cogstream_amd import ops
+    with pytest.raises(L.CogsError):
+        ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64))
+    with pytest.raises(L.CogsError):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16))
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "cogstream_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_resize_table_and_patchify():
+    """size table of SURVEY.md section 8 (computed from image_processing_videollama3.py:93-131)"""
+    from cogstream_amd import processing as pr
+    assert pr.simple_batched_resize([(224, 224)], 8) == [(224, 224)]
+    assert pr.simple_batched_resize([(480, 854)], 64) == [(308, 588)]
+    assert pr.simple_batched_resize([(480, 854)], 256) == [(140, 280)]
+    assert pr.simple_batched_resize([(480, 640)], 64) == [(364, 504)]
+    # patchify round trip: row r <-> (frame, merge-row, merge-col, window, c, py, px)
+    t, gh, gw, ms = 2, 4, 6, 2
+    img = np.arange(t * 3 * gh * 14 * gw * 14, dtype=np.float32).reshape(t, 3, gh * 14, gw * 14)
+    rows = pr.patchify(img, ms)
+    assert rows.shape == (t * gh * gw, 588)
+    from oracle import vision as ov
+    order = ov.patchify_order(t, gh, gw, ms)
+    for r in (0, 1, 2, 3, 4, 17, 47):
+        f, pr_, pc = order[r].tolist()
+        patch = img[f, :, pr_ * 14:(pr_ + 1) * 14, pc * 14:(pc + 1) * 14].reshape(-1)
+        assert np.array_equal(rows[r], patch)
+
+
+def test_preprocess_synthetic_clip_shapes():
+    from cogstream_amd import processing as pr
+    frames, ts = pr.synthetic_clip(8, 224, 224)
+    out = pr.preprocess_videos([frames])
+    assert out["pixel_values"].shape == (2048, 588) and out["grid_sizes"].tolist() == [[8, 16, 16]]
+    assert out["pixel_values"].dtype == np.float32 and abs(out["pixel_values"]).max() <= 1.0
+    d, _ = pr.synthetic_clip(4, 56, 56, kind="drift")
+    assert d.shape == (4, 56, 56, 3)
+
+
+def test_chat_template_rendering():
+    """SURVEY.md appendix B3 (rendered by the reference's chat template)"""
+    from cogstream_amd import processing as pr
+    conv = [{"role": "system", "content": "You are a helpful assistant."},
+            {"role": "user", "content": [{"type": "video", "num_frames": 3, "timestamps": [0.0, 1.0, 2.04]},
+                                         {"type": "text", "text": "Q1?"}]},
+            {"role": "assistant", "content": "A1."},
+            {"role": "user", "content": "Q2?"}]
+    want = ("<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\nTime 0.0s:<image>,Time 1.0s:<image>,"
+            "Time 2.0s:<image>\nQ1?<|im_end|>\n<|im_start|>assistant\nA1.<|im_end|>\n<|im_start|>user\nQ2?<|im_end|>\n"
+            "<|im_start|>assistant\n")
+    assert pr.render_conversation(conv) == want
+    assert pr.expand_image_tokens("a<image>b<image>", [2, 1]) == "a<image><image>b<image>"
+    assert pr.process_history_qas(conv) == (["Q1?"], ["A1."], "Q2?")
+    no_sys = pr.render_conversation(conv[1:2], add_generation_prompt=False)
+    assert no_sys.startswith("<|im_start|>system\nYou are VideoLLaMA3 created by Alibaba DAMO Academy")
+
+
+def test_processor_call_contract():
+    from cogstream_amd import processing as pr
+    from toy_tokenizer import IMAGE, ToyTokenizer
+    frames, ts = pr.synthetic_clip(4, 56, 56)
+    conv = [{"role": "user", "content": [{"type": "video", "video": frames, "timestamps": ts}, {"type": "text", "text": "What?"}]}]
+    out = pr.CogStreamProcessor(ToyTokenizer())(conversation=conv)
+    for k in ("input_ids", "attention_mask", "pixel_values", "grid_sizes", "merge_sizes", "modals", "tokenizer", "hist_qs",
+              "hist_as", "current_question", "all_timestamps", "total_image_num", "original_text"):
+        assert k in out, k
+    gs, ms = out["grid_sizes"], out["merge_sizes"]
+    n_tok = int((gs.prod(1) // (ms ** 2)).sum())
+    assert int((out["input_ids"] == IMAGE).sum()) == n_tok          # processing_cogreasoner.py:606,727
+    assert out["total_image_num"] == 4 and out["current_question"] == "What?" and out["hist_qs"] == []
+
+
+def test_frame_shards():
+    from cogstream_amd.parallel import frame_shards
+    assert frame_shards(64, 8) == [(8 * i, 8 * i + 8) for i in range(8)]
+    assert frame_shards(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]

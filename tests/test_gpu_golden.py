@@ -1,0 +1,150 @@
+"""HIP path (through the C ABI / host mirror) against the fixtures produced by running the reference
+(tests/golden/make_golden.py). Integer outputs -- cluster assignments, selected frames, keep-masks,
+compacted ids, generated token ids, selection strings -- must be BIT-EXACT; floating point is compared in
+fp32 parity mode at 1e-4 relative (the north-star logit tolerance is 1e-3) and in bf16 at bf16 precision."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+VIT = dict(hidden_size=576, intermediate_size=200, num_hidden_layers=2, num_attention_heads=8)
+LLM = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+           num_key_value_heads=1, vocab_size=512, image_token_index=258, eos_token_id=257)
+
+
+def _load(name):
+    return {k: v for k, v in np.load(os.path.join(G, name), allow_pickle=False).items()}
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+def test_vit_and_projector_vs_reference(dev, dtype, tol):
+    from cogstream_amd.vision import BLOCK_DIAG, REF_EAGER_GLOBAL, Projector, VisionEncoder
+    from cogstream_amd.weights import VisionConfig, random_proj_state, random_vit_state
+    g = _load("vit_tiny.npz")
+    cfg = VisionConfig(**VIT)
+    enc = VisionEncoder(random_vit_state(cfg, seed=3, std=0.05), cfg, dtype=dtype, device=dev)
+    pix = torch.from_numpy(g["pixel_values"]).to(dev)
+    grid, merge = torch.from_numpy(g["grid_sizes"]), torch.from_numpy(g["merge_sizes"])
+    eg = enc(pix, grid, merge, attn_mode=REF_EAGER_GLOBAL)
+    bd = enc(pix, grid, merge, attn_mode=BLOCK_DIAG)
+    assert rel_err(eg.float(), torch.from_numpy(g["eager_global"])) < tol
+    assert rel_err(bd.float(), torch.from_numpy(g["block_diag"])) < tol
+    proj = Projector(random_proj_state(cfg.hidden_size, 256, seed=1, std=0.05), dtype=dtype, device=dev)
+    assert rel_err(proj(bd).float(), torch.from_numpy(g["projected"])) < tol
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_kmeans_vs_reference(dev, ci):
+    from cogstream_amd.kmeans import kmeans_with_time_min_max, select_additional_frames
+    g = _load("kmeans.npz")
+    feats = torch.from_numpy(g[f"c{ci}_features"])
+    if int(g[f"c{ci}_is_bf16"]):
+        feats = feats.bfloat16()
+    ts, K, seed = torch.from_numpy(g[f"c{ci}_ts"]), int(g[f"c{ci}_K"]), int(g[f"c{ci}_seed"])
+    random.seed(seed)
+    torch.manual_seed(seed)
+    cf, ct, assign = kmeans_with_time_min_max(feats.to(dev), ts, K)
+    assert rel_err(cf.float(), torch.from_numpy(g[f"c{ci}_centres"])) < 1e-5
+    assert rel_err(ct, torch.from_numpy(g[f"c{ci}_centre_ts"])) < 1e-6
+    if f"c{ci}_assign" in g:
+        assert torch.equal(assign.cpu(), torch.from_numpy(g[f"c{ci}_assign"]))          # bit-exact cluster indices
+        sel = select_additional_frames(feats.to(dev), cf, assign, 2)
+        assert torch.equal(torch.cat(sel).cpu().sort().values, torch.from_numpy(g[f"c{ci}_extra"]))
+        assert [len(s) for s in sel] == g[f"c{ci}_extra_counts"].tolist()
+    else:
+        assert assign is None
+
+
+def _tiny_model(dev, dtype, attn_mode):
+    from cogstream_amd.chat import CogReasoner
+    from cogstream_amd.llm import Qwen2Engine
+    from cogstream_amd.vision import Projector, VisionEncoder
+    from cogstream_amd.weights import LlmConfig, VisionConfig, random_llm_state, random_proj_state, random_vit_state
+    vcfg, lcfg = VisionConfig(**VIT), LlmConfig(**LLM)
+    enc = VisionEncoder(random_vit_state(vcfg, seed=3, std=0.05), vcfg, dtype=dtype, device=dev, attn_mode=attn_mode)
+    proj = Projector(random_proj_state(vcfg.hidden_size, lcfg.hidden_size, seed=1, std=0.05), dtype=dtype, device=dev)
+    eng = Qwen2Engine(random_llm_state(lcfg, seed=7, std=0.05), lcfg, dtype=dtype, device=dev)
+    return CogReasoner(enc, proj, eng, lcfg, generation_config=dict(do_sample=False, repetition_penalty=1.05,
+                                                                    eos_token_id=[257]))
+
+
+def test_compression_vs_reference(dev):
+    g = _load("compress.npz")
+    model = _tiny_model(dev, torch.float32, 0)
+    pix = torch.from_numpy(g["pixel_values"])
+    grid, merge = torch.from_numpy(g["grid_sizes"]), torch.from_numpy(g["merge_sizes"])
+    batched = grid.prod(dim=1).div(merge ** 2).long()
+    for tag, px in (("f32", pix), ("bf16", pix.bfloat16())):
+        m = model._get_compression_mask(px.to(dev), batched, grid, merge, ["video"], minor_frame_indices=[])
+        assert torch.equal(m.cpu(), torch.from_numpy(g[f"mask_{tag}"]))
+        m = model._get_compression_mask(px.to(dev), batched, grid, merge, ["video"], minor_frame_indices=[2, 5])
+        assert torch.equal(m.cpu(), torch.from_numpy(g[f"mask_minor_{tag}"]))
+    ev = model.compress_unimportant_events(torch.from_numpy(g["mm"]).to(dev), 6, [1, 4])
+    assert rel_err(ev, torch.from_numpy(g["event_pooled"])) < 1e-6
+    rows, ids2, _ = model._compress_visual_tokens(torch.from_numpy(g["mask_minor_f32"]), torch.from_numpy(g["input_ids"]), None)
+    assert torch.equal(ids2, torch.from_numpy(g["ids_compressed"]))
+    assert torch.equal(torch.from_numpy(g["event_pooled"])[rows], torch.from_numpy(g["mm_compressed"]))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_end_to_end_vs_reference(dev, tag):
+    """qa_selection -> generate, fp32 parity mode with the reference's CPU attention semantics
+    (REF_EAGER_GLOBAL), toy tokenizer, greedy. a: 8 frames + history (retrieval, prompt surgery);
+    b: 150 frames (k-means, 10 event passes); c: b with forced event/question cosines (event compression)."""
+    from golden.inputs import FORCED_COSINE, e2e_inputs
+    from toy_tokenizer import ToyTokenizer
+    g = _load("e2e.npz")
+    inp = e2e_inputs(tag)
+    assert abs(float(inp["pixel_values"].double().abs().sum()) - float(g[f"{tag}_pix_checksum"])) < 1e-6
+    model = _tiny_model(dev, torch.float32, 1)
+    tok = ToyTokenizer()
+    enc = tok(inp["text"])
+    random.seed(5)
+    torch.manual_seed(5)
+    sel = model.qa_selection(current_question=inp["current_question"], hist_qs=inp["hist_qs"], hist_as=inp["hist_as"],
+                             tokenizer=tok, original_text=inp["text"], input_ids=enc["input_ids"],
+                             attention_mask=enc["attention_mask"], mode="FCC", all_timestamps=inp["timestamps"])
+    assert sel["selection_module_output"] == str(g[f"{tag}_selection"])
+    assert sel["if_visual"] == bool(g[f"{tag}_if_visual"])
+    assert torch.equal(sel["new_input_ids"][0], torch.from_numpy(g[f"{tag}_new_input_ids"]))
+    model.cosine_override = FORCED_COSINE if tag == "c" else None
+    ids, sel_out = model.generate(pixel_values=inp["pixel_values"], grid_sizes=inp["grid_sizes"],
+                                  merge_sizes=inp["merge_sizes"], modals=["video"], new_input_ids=sel["new_input_ids"],
+                                  new_attention_mask=sel["new_attention_mask"],
+                                  selection_module_output=sel["selection_module_output"], if_visual=sel["if_visual"],
+                                  total_image_num=inp["T"], max_new_tokens=8)
+    dbg = model.last_debug
+    assert dbg["minor_frames"] == g[f"{tag}_minor"].tolist()                           # bit-exact frame indices
+    assert torch.equal(dbg["compression_mask"].cpu(), torch.from_numpy(g[f"{tag}_mask"]))
+    if tag in ("b", "c"):
+        assert dbg["assign"] == g[f"{tag}_assign"].tolist()                            # bit-exact cluster indices
+        assert rel_err(dbg["cosine_raw"], torch.from_numpy(g[f"{tag}_cosine"])) < 1e-3
+    assert ids.shape[0] == 1 and ids[0].tolist() == g[f"{tag}_tokens"].tolist()        # greedy tokens
+    assert sel_out == str(g[f"{tag}_sel_out"])
+
+
+def test_end_to_end_bf16_block_diag_runs(dev):
+    """production configuration (bf16, per-frame attention): same control flow, integer products stay sane"""
+    from golden.inputs import e2e_inputs
+    from toy_tokenizer import ToyTokenizer
+    inp = e2e_inputs("b")
+    model = _tiny_model(dev, torch.bfloat16, 0)
+    tok = ToyTokenizer()
+    enc = tok(inp["text"])
+    random.seed(5)
+    torch.manual_seed(5)
+    sel = model.qa_selection(current_question=inp["current_question"], hist_qs=[], hist_as=[], tokenizer=tok,
+                             original_text=inp["text"], input_ids=enc["input_ids"], attention_mask=enc["attention_mask"],
+                             mode="FCC", all_timestamps=inp["timestamps"])
+    ids, _ = model.generate(pixel_values=inp["pixel_values"].bfloat16(), grid_sizes=inp["grid_sizes"],
+                            merge_sizes=inp["merge_sizes"], modals=["video"], new_input_ids=sel["new_input_ids"],
+                            new_attention_mask=sel["new_attention_mask"], if_visual=True, total_image_num=inp["T"],
+                            max_new_tokens=4)
+    assert ids.shape == (1, 4) or ids.shape[1] <= 4
+    assert len(model.last_debug["assign"]) == 150 and int(model.last_debug["compression_mask"].sum()) > 150

@@ -1,0 +1,114 @@
+"""Pin the oracle (CPU restatement) against fixtures produced by RUNNING THE REFERENCE
+(tests/golden/make_golden.py, build container only). fp32 on both sides: tolerances are summation-order
+noise; integer outputs (assignments, masks, ids) must be bit-exact."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+VIT = dict(hidden_size=576, intermediate_size=200, num_hidden_layers=2, num_attention_heads=8)
+
+
+def _load(name):
+    return {k: v for k, v in np.load(os.path.join(G, name), allow_pickle=False).items()}
+
+
+def test_vit_oracle_matches_reference():
+    from cogstream_amd.weights import VisionConfig, random_proj_state, random_vit_state
+    from oracle import vision as ov
+    g = _load("vit_tiny.npz")
+    cfg = VisionConfig(**VIT)
+    st = random_vit_state(cfg, seed=3, std=0.05)
+    assert abs(float(sum(v.double().abs().sum() for v in st.values())) - float(g["vit_checksum"])) < 1e-6
+    pix, grid, merge = torch.from_numpy(g["pixel_values"]), torch.from_numpy(g["grid_sizes"]), torch.from_numpy(g["merge_sizes"])
+    kw = dict(heads=cfg.num_attention_heads, layers=cfg.num_hidden_layers)
+    eg = ov.encode(st, pix, grid, merge, mode=ov.REF_EAGER_GLOBAL, **kw)
+    bd = ov.encode(st, pix, grid, merge, mode=ov.BLOCK_DIAG, **kw)
+    assert rel_err(eg, torch.from_numpy(g["eager_global"])) < 2e-5
+    assert rel_err(bd, torch.from_numpy(g["block_diag"])) < 2e-5
+    # the two attention semantics really differ (SURVEY.md headline fact 2)
+    assert rel_err(eg, bd) > 1e-3
+    pst = random_proj_state(cfg.hidden_size, 256, seed=1, std=0.05)
+    assert rel_err(ov.project(pst, bd), torch.from_numpy(g["projected"])) < 2e-5
+
+
+def test_rope_and_patch_order_contracts():
+    """SURVEY.md appendix B1/B2 (probed on the reference)"""
+    from oracle import vision as ov
+    ids = ov.rot_pos_ids(torch.tensor([[1, 4, 6]]), torch.tensor([2]))
+    assert ids[:8].tolist() == [[0, 0], [0, 1], [1, 0], [1, 1], [0, 2], [0, 3], [1, 2], [1, 3]]
+    order = ov.patchify_order(2, 4, 6, 2)
+    assert order[:5].tolist() == [[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [0, 0, 2]]
+    f = ov.rotary_freqs(torch.tensor([[1, 4, 6]]), torch.tensor([2]), 72)
+    assert f.shape == (24, 36)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 36, 2).float() / 36))
+    assert torch.allclose(inv[:4], torch.tensor([1.0, 0.59948, 0.35938, 0.21544]), atol=1e-5)
+    assert torch.allclose(f[3], torch.cat([1 * inv, 1 * inv]))  # row 3 = (h=1, w=1)
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_kmeans_oracle_matches_reference(ci):
+    from oracle import kmeans as ok
+    g = _load("kmeans.npz")
+    feats = torch.from_numpy(g[f"c{ci}_features"])
+    if int(g[f"c{ci}_is_bf16"]):
+        feats = feats.bfloat16()
+    ts, K, seed = torch.from_numpy(g[f"c{ci}_ts"]), int(g[f"c{ci}_K"]), int(g[f"c{ci}_seed"])
+    random.seed(seed)
+    torch.manual_seed(seed)
+    cf, ct, assign = ok.kmeans_with_time_min_max(feats, ts, K)
+    assert rel_err(cf.float(), torch.from_numpy(g[f"c{ci}_centres"])) < 1e-5
+    assert rel_err(ct, torch.from_numpy(g[f"c{ci}_centre_ts"])) < 1e-6
+    if f"c{ci}_assign" in g:
+        assert torch.equal(assign, torch.from_numpy(g[f"c{ci}_assign"]))
+        sel = ok.select_additional_frames(feats, cf, assign, 2)
+        assert torch.equal(torch.cat(sel).sort().values, torch.from_numpy(g[f"c{ci}_extra"]))
+        assert [len(s) for s in sel] == g[f"c{ci}_extra_counts"].tolist()
+    else:
+        assert assign is None
+
+
+def test_compress_oracle_matches_reference():
+    from oracle import compress as oc
+    g = _load("compress.npz")
+    pix = torch.from_numpy(g["pixel_values"])
+    grid, merge = torch.from_numpy(g["grid_sizes"]), torch.from_numpy(g["merge_sizes"])
+    for tag, px in (("f32", pix), ("bf16", pix.bfloat16())):
+        assert torch.equal(oc.compression_mask(px, grid, merge, ["video"]), torch.from_numpy(g[f"mask_{tag}"]))
+        assert torch.equal(oc.compression_mask(px, grid, merge, ["video"], minor_frame_indices=[2, 5]),
+                           torch.from_numpy(g[f"mask_minor_{tag}"]))
+    m = torch.from_numpy(g["mask_f32"])
+    assert 0 < int(m.sum()) < m.numel()
+    mm = torch.from_numpy(g["mm"])
+    ev = oc.compress_unimportant_events(mm, 6, [1, 4])
+    assert torch.equal(ev, torch.from_numpy(g["event_pooled"]))
+    mm2, ids2, _ = oc.compress_visual_tokens(torch.from_numpy(g["mask_minor_f32"]), ev, torch.from_numpy(g["input_ids"]),
+                                             None, 258)
+    assert torch.equal(ids2, torch.from_numpy(g["ids_compressed"])) and torch.equal(mm2, torch.from_numpy(g["mm_compressed"]))
+
+
+def test_host_text_logic_matches_reference():
+    """prompt surgery / prompts are host logic of the product (cogstream_amd.chat / qaselect): same strings"""
+    from cogstream_amd.chat import create_visual_summary_prompt, parse_selection, process_input_ids
+    from cogstream_amd.qaselect import format_example
+    from toy_tokenizer import ToyTokenizer
+    tok = ToyTokenizer()
+    t = json.load(open(os.path.join(G, "text.json")))
+    for c in t["cases"]:
+        vis, sel = parse_selection(c["selection"])
+        hq = [t["hist_qs"][i] for i in sel if i < len(t["hist_qs"])]
+        ha = [t["hist_as"][i] for i in sel if i < len(t["hist_qs"])]
+        out = process_input_ids(t["original_text"], vis, hq, ha, t["current_question"])
+        assert vis == c["if_visual"], c["selection"]
+        assert out == c["prompt"], c["selection"]
+        assert tok.encode(out) == c["ids"]
+    assert create_visual_summary_prompt(6, torch.tensor([0.0, 1.04, 12.5])) == t["summary_prompt"]
+    ex = {"current_Q": t["current_question"], "hist_Qs": t["hist_qs"], "hist_As": t["hist_as"]}
+    assert format_example(ex) == t["qa_prompt"]
+    assert format_example(ex, include_demo=False) == t["qa_prompt_nodemo"]
