@@ -70,8 +70,9 @@ def _tiny_model(dev, dtype, attn_mode):
     enc = VisionEncoder(random_vit_state(vcfg, seed=3, std=0.05), vcfg, dtype=dtype, device=dev, attn_mode=attn_mode)
     proj = Projector(random_proj_state(vcfg.hidden_size, lcfg.hidden_size, seed=1, std=0.05), dtype=dtype, device=dev)
     eng = Qwen2Engine(random_llm_state(lcfg, seed=7, std=0.05), lcfg, dtype=dtype, device=dev)
-    return CogReasoner(enc, proj, eng, lcfg, generation_config=dict(do_sample=False, repetition_penalty=1.05,
-                                                                    eos_token_id=[257]))
+    # like the reference's freshly built tiny model: default GenerationConfig (greedy, no penalty); the answer
+    # generation passes repetition_penalty=1.05 explicitly, exactly as make_golden.py does
+    return CogReasoner(enc, proj, eng, lcfg, generation_config=dict(do_sample=False, eos_token_id=[257]))
 
 
 def test_compression_vs_reference(dev):
@@ -118,7 +119,7 @@ def test_end_to_end_vs_reference(dev, tag):
                                   merge_sizes=inp["merge_sizes"], modals=["video"], new_input_ids=sel["new_input_ids"],
                                   new_attention_mask=sel["new_attention_mask"],
                                   selection_module_output=sel["selection_module_output"], if_visual=sel["if_visual"],
-                                  total_image_num=inp["T"], max_new_tokens=8)
+                                  total_image_num=inp["T"], max_new_tokens=8, repetition_penalty=1.05)
     dbg = model.last_debug
     assert dbg["minor_frames"] == g[f"{tag}_minor"].tolist()                           # bit-exact frame indices
     assert torch.equal(dbg["compression_mask"].cpu(), torch.from_numpy(g[f"{tag}_mask"]))
