@@ -24,6 +24,7 @@ struct CogsGemm {
     const float* rope_sin = nullptr;
     int rope_cols = 0;
     int head_dim = 0;
+    int force_small_tile = 0;                // testing: always use the 128x128 kernel
 };
 int cogs_k_gemm(hipStream_t st, const CogsGemm& g);
 

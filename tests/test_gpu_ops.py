@@ -23,7 +23,8 @@ def _L():
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1.2e-2), (torch.float32, 2e-5)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1, 512, 256), (77, 132, 128), (1024, 1152, 1152)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1, 512, 256), (77, 132, 128), (1024, 1152, 1152),
+                                   (515, 132, 64), (777, 384, 704)])
 def test_gemm_bias_residual(dev, dtype, tol, M, N, K):
     ops = _ops()
     torch.manual_seed(M * 7 + N)
@@ -39,8 +40,12 @@ def test_gemm_bias_residual(dev, dtype, tol, M, N, K):
 
 def test_gemm_integer_exact(dev):
     """MFMA fragment/layout check with exactly representable data and an asymmetric W"""
+    run_gemm_integer_exact(dev, 256, 256, 128)
+    run_gemm_integer_exact(dev, 1024 + 40, 384, 448)   # 256x128 ring-buffered variant, ragged M
+
+
+def run_gemm_integer_exact(dev, M, N, K):
     ops = _ops()
-    M, N, K = 256, 256, 128
     a = torch.randint(-3, 4, (M, K)).float()
     w = (torch.arange(N)[:, None] % 5 - 2).float() * torch.randint(0, 2, (N, K)).float() + (torch.arange(K)[None, :] % 3).float()
     ref = a @ w.t()
