@@ -192,44 +192,73 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
             }
         }
 
-        // online softmax; lane holds keys kbase + 32u + 8g + 4t + reg of query column li
+        // online softmax; lane holds keys kbase + 32u + 8g + 4t + reg of query column li.
+        // Masking (key range, causal diagonal, same-segment bias) is only evaluated on tiles that need it:
+        // the test is block-uniform, so interior tiles run a compare-free body (max, fma, v_exp, add).
         bf16x8 pf[2][2];
+        const bool need_mask = (kbase + 64 > ke) || (p.row_lo != nullptr) ||
+                               (p.causal && (kbase + 63 - ks) > (q0 - qs) + p.q_pos0);
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            const int qloc = qrow[qi] - qs;
             float sv[4][4];
             float mx = -INFINITY;
+            if (need_mask) {
+                const int qloc = qrow[qi] - qs;
 #pragma unroll
-            for (int ut = 0; ut < 4; ++ut)
+                for (int ut = 0; ut < 4; ++ut)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kbase + 32 * (ut >> 1) + 8 * g + 4 * (ut & 1) + r;
-                    bool valid = key < ke;
-                    if (p.causal) valid = valid && (key - ks) <= qloc + p.q_pos0;
-                    float s = sacc[ut][qi][r] * p.scale_log2;
-                    if (p.row_lo && key >= blo[qi] && key < bhi[qi]) s += p.bias_log2;
-                    s = valid ? s : -INFINITY;
-                    sv[ut][r] = s;
-                    mx = fmaxf(mx, s);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kbase + 32 * (ut >> 1) + 8 * g + 4 * (ut & 1) + r;
+                        bool valid = key < ke;
+                        if (p.causal) valid = valid && (key - ks) <= qloc + p.q_pos0;
+                        float sc = sacc[ut][qi][r] * p.scale_log2;
+                        if (p.row_lo && key >= blo[qi] && key < bhi[qi]) sc += p.bias_log2;
+                        sc = valid ? sc : -INFINITY;
+                        sv[ut][r] = sc;
+                        mx = fmaxf(mx, sc);
+                    }
+            } else {
+#pragma unroll
+                for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[ut][qi][r]);
+                mx *= p.scale_log2;   // scale > 0
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[qi], mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = exp2f(m_run[qi] - m_use);
             float psum = 0.f;
+            if (need_mask) {
 #pragma unroll
-            for (int ut = 0; ut < 4; ++ut)
+                for (int ut = 0; ut < 4; ++ut)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2f(sv[ut][r] - m_use);
-                    sv[ut][r] = pv;
-                    psum += pv;
-                }
-            l_run[qi] = l_run[qi] * alpha + psum;
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(sv[ut][r] - m_use);
+                        sv[ut][r] = pv;
+                        psum += pv;
+                    }
+            } else {
+#pragma unroll
+                for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[ut][qi][r], p.scale_log2, -m_use));
+                        sv[ut][r] = pv;
+                        psum += pv;
+                    }
+            }
+            // the running maximum rarely moves after the first tiles: skip the O rescale when no row of
+            // this wave changed it (wave-uniform vote; alpha is exactly 1 in that case)
+            if (__any(m_new != m_run[qi])) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_use);
+                l_run[qi] = l_run[qi] * alpha + psum;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) oacc[d][qi] *= alpha;
+            } else {
+                l_run[qi] += psum;
+            }
             m_run[qi] = m_new;
-#pragma unroll
-            for (int d = 0; d < DT; ++d) oacc[d][qi] *= alpha;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 u32x4 w;
