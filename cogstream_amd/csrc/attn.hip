@@ -21,6 +21,7 @@
 // fp32 / generic kernel: one wave per (query row, head), two passes; parity mode only.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -81,9 +82,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
             *reinterpret_cast<u32x4*>(Ks + row * 256 + ((c ^ k_swz(row)) << 4)) = u32x4{0, 0, 0, 0};
         }
     }
-    if (HD % 16 != 0) {
+    // hd 72: the 8 pad columns of V hold [1, 0, ...]: row d = HD of O^T then accumulates sum_key P[key][q],
+    // i.e. the softmax denominator comes out of the PV MFMAs for free (and is rescaled with O)
+    constexpr bool SUM_IN_V = (HD % 16 != 0);
+    if (SUM_IN_V) {
         for (int row = tid; row < 64; row += 256)
-            *reinterpret_cast<u32x4*>(Vs + (row >> 3) * VG + (row & 7) * VS + CH * 16) = u32x4{0, 0, 0, 0};
+            *reinterpret_cast<u32x4*>(Vs + (row >> 3) * VG + (row & 7) * VS + CH * 16) = u32x4{0x00003f80u, 0, 0, 0};
     }
 
     // Q fragments (B operand of S^T = K.Q^T): lane (q = li, g) holds Q[q][32s + 8g + j]
@@ -131,20 +135,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
             if (qok[qi]) { blo[qi] = p.row_lo[qrow[qi]]; bhi[qi] = p.row_hi[qrow[qi]]; }
     }
 
+    // register staging of the next K/V tile; per-thread chunk coordinates are loop invariant
     u32x4 kreg[PER], vreg[PER];
+    int k_goff[PER], v_goff[PER];   // element offsets inside one tile (row < 64): 32 bits are plenty
+    int st_row[PER], k_loff[PER], v_loff[PER];
+    bool st_ok[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int id = tid + i * 256;
+        st_ok[i] = id < NCH;
+        const int row = st_ok[i] ? id / CH : 0, c = st_ok[i] ? id % CH : 0;
+        st_row[i] = row;
+        k_goff[i] = row * (int)p.ldk + kvh * HD + c * 8;
+        v_goff[i] = row * (int)p.ldv + kvh * HD + c * 8;
+        k_loff[i] = row * 256 + ((c ^ k_swz(row)) << 4);
+        v_loff[i] = (row >> 3) * VG + (row & 7) * VS + c * 16;
+    }
     auto load_tile = [&](int kt) {
         const int kbase = ks + kt * 64;
+        const bf16_t* kb = Kp + (long)kbase * p.ldk;
+        const bf16_t* vb = Vp + (long)kbase * p.ldv;
+        if (kbase + 64 <= ke) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int id = tid + i * 256;
-            kreg[i] = u32x4{0, 0, 0, 0};
-            vreg[i] = u32x4{0, 0, 0, 0};
-            if (id < NCH) {
-                const int row = id / CH, c = id % CH;
-                const int key = kbase + row;
-                if (key < ke) {
-                    kreg[i] = *reinterpret_cast<const u32x4*>(Kp + (long)key * p.ldk + kvh * HD + c * 8);
-                    vreg[i] = *reinterpret_cast<const u32x4*>(Vp + (long)key * p.ldv + kvh * HD + c * 8);
+            for (int i = 0; i < PER; ++i) {
+                if (i + 1 < PER || NCH % 256 == 0 || st_ok[i]) {
+                    kreg[i] = *reinterpret_cast<const u32x4*>(kb + k_goff[i]);
+                    vreg[i] = *reinterpret_cast<const u32x4*>(vb + v_goff[i]);
+                }
+            }
+        } else {   // partial tile: rows past the key range are zero filled
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                kreg[i] = u32x4{0, 0, 0, 0};
+                vreg[i] = u32x4{0, 0, 0, 0};
+                if (st_ok[i] && kbase + st_row[i] < ke) {
+                    kreg[i] = *reinterpret_cast<const u32x4*>(kb + k_goff[i]);
+                    vreg[i] = *reinterpret_cast<const u32x4*>(vb + v_goff[i]);
                 }
             }
         }
@@ -152,11 +178,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
     auto write_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int id = tid + i * 256;
-            if (id < NCH) {
-                const int row = id / CH, c = id % CH;
-                *reinterpret_cast<u32x4*>(Ks + row * 256 + ((c ^ k_swz(row)) << 4)) = kreg[i];
-                *reinterpret_cast<u32x4*>(Vs + (row >> 3) * VG + (row & 7) * VS + c * 16) = vreg[i];
+            if (i + 1 < PER || NCH % 256 == 0 || st_ok[i]) {
+                *reinterpret_cast<u32x4*>(Ks + k_loff[i]) = kreg[i];
+                *reinterpret_cast<u32x4*>(Vs + v_loff[i]) = vreg[i];
             }
         }
     };
@@ -168,7 +192,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
     const int vrow_off = g * VG + (li >> 2) * VS + (li & 3) * 8;
 
     if (t_begin < nt) load_tile(t_begin);
-    for (int kt = t_begin; kt < nt; ++kt) {
+    // one K/V tile; MASKED is a compile-time tag: interior tiles run a compare-free softmax body, only the
+    // tiles that touch the key-range end, the causal diagonal or the bias mode evaluate masks. (A run-time
+    // uniform branch gets if-converted by hipcc into one block that executes both bodies.)
+    auto process_tile = [&](const int kt, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         __syncthreads();
         write_tile();
         __syncthreads();
@@ -176,8 +204,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
 
         const int kbase = ks + kt * 64;
         f32x4 sacc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { sacc[i][0] = f32x4{0, 0, 0, 0}; sacc[i][1] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
         for (int ut = 0; ut < 4; ++ut) {
             const int krow = 32 * (ut >> 1) + 4 * (ut & 1) + krow0;
@@ -188,7 +214,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi)
                     sacc[ut][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, kf), qf[qi][s], sacc[ut][qi], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8, kf), qf[qi][s],
+                        s == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[ut][qi], 0, 0, 0);   // C = 0 is an inline constant
             }
         }
 
@@ -196,13 +223,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
         // Masking (key range, causal diagonal, same-segment bias) is only evaluated on tiles that need it:
         // the test is block-uniform, so interior tiles run a compare-free body (max, fma, v_exp, add).
         bf16x8 pf[2][2];
-        const bool need_mask = (kbase + 64 > ke) || (p.row_lo != nullptr) ||
-                               (p.causal && (kbase + 63 - ks) > (q0 - qs) + p.q_pos0);
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             float sv[4][4];
             float mx = -INFINITY;
-            if (need_mask) {
+            if constexpr (MASKED) {
                 const int qloc = qrow[qi] - qs;
 #pragma unroll
                 for (int ut = 0; ut < 4; ++ut)
@@ -229,14 +254,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
             const float m_new = fmaxf(m_run[qi], mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             float psum = 0.f;
-            if (need_mask) {
+            if constexpr (MASKED) {
 #pragma unroll
                 for (int ut = 0; ut < 4; ++ut)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = __builtin_amdgcn_exp2f(sv[ut][r] - m_use);
                         sv[ut][r] = pv;
-                        psum += pv;
+                        if (!SUM_IN_V) psum += pv;
                     }
             } else {
 #pragma unroll
@@ -245,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
                     for (int r = 0; r < 4; ++r) {
                         const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[ut][qi][r], p.scale_log2, -m_use));
                         sv[ut][r] = pv;
-                        psum += pv;
+                        if (!SUM_IN_V) psum += pv;
                     }
             }
             // the running maximum rarely moves after the first tiles: skip the O rescale when no row of
@@ -289,7 +314,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
                     oacc[d][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][qi], oacc[d][qi], 0, 0, 0);
             }
         }
+    };
+
+    // leading tiles [t_begin, t_mid) need no mask: fully inside the key range and left of the causal diagonal
+    int t_mid = t_begin;
+    if (!p.row_lo) {
+        int full = (ke - ks) / 64;
+        if (p.causal) {
+            const int lim = (q0 - qs) + p.q_pos0 - 63;   // tile kt is unmasked iff 64*kt <= lim
+            full = min(full, lim >= 0 ? lim / 64 + 1 : 0);
+        }
+        t_mid = max(t_begin, min(full, nt));
     }
+    for (int kt = t_begin; kt < t_mid; ++kt) process_tile(kt, std::false_type{});
+    for (int kt = t_mid; kt < nt; ++kt) process_tile(kt, std::true_type{});
 
     bf16_t* Op = reinterpret_cast<bf16_t*>(p.O);
 #pragma unroll
@@ -297,6 +335,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
         float l = l_run[qi];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
+        if (SUM_IN_V) {
+            // row d = HD of O^T lives in d-tile HD/16, lane group (HD%16)/4, register 0
+            l = __shfl(oacc[HD / 16][qi][0], li + 16 * ((HD % 16) / 4), 64);
+        }
         if (!qok[qi]) continue;
         if (p.nsplit > 1) {
             const long slot = ((long)split * p.q_len + qrow[qi]) * p.hq + qhead[qi];
