@@ -6,7 +6,9 @@ import ctypes as C
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libcogs_hip.so"
+import os as _os
+
+LIB_PATH = Path(_os.environ.get("COGS_LIB_PATH", str(_HERE / "libcogs_hip.so")))  # override: A/B experiments only
 
 DT_BF16, DT_F32 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3

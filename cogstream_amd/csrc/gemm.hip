@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs p) {
 constexpr int BM2 = 256;
 constexpr int SLAB2 = (BM2 + BN) * ROW_BYTES;   // 48 KiB per K slab (A 32 KiB then W 16 KiB)
 constexpr int PIECES2 = SLAB2 / 1024 / 8;       // 6 LDS-DMA pieces per wave per slab
+constexpr int PERSISTENT_WGS = 256;             // one workgroup per CU (MI355X: 256 CUs)
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_tn_256x128_kernel(GemmArgs p) {
@@ -197,55 +198,63 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x128_kernel(GemmArgs p) {
     const int lane = tid & 63;
     const int wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-
     const int nb = p.nbm * p.nbn;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nb >> 3, r = nb & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int per_group = GROUP_M * p.nbn;
-    const int grp = bid / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsz = min(p.nbm - first_m, GROUP_M);
-    const int tm = first_m + (bid % per_group) % gsz;
-    const int tn = (bid % per_group) / gsz;
-    const int m0 = tm * BM2, n0 = tn * BN;
+    const int KT = p.K / BK;
 
+    // PERSISTENT: this workgroup walks tiles t = blockIdx.x, +gridDim.x, ... of the XCD-aware order; the
+    // K-slab ring runs continuously ACROSS tiles, so the next tile's first slabs stream in while the
+    // current tile finishes and runs its epilogue (no per-tile prologue bubble).
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int xcd = t & 7, q = nb >> 3, r = nb & 7;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+        const int per_group = GROUP_M * p.nbn;
+        const int first_m = (bid / per_group) * GROUP_M;
+        const int gsz = min(p.nbm - first_m, GROUP_M);
+        m0 = (first_m + (bid % per_group) % gsz) * BM2;
+        n0 = ((bid % per_group) / gsz) * BN;
+    };
+
+    // staging iterator: (tile st_t, slab st_kt) with that tile's per-lane source pointers.
     // piece pc (0..47) of a slab: pc < 32 -> A rows 8pc..8pc+7, else W rows 8(pc-32)..; wave w owns 6w..6w+5
     const char* src[PIECES2];
+    int st_t = blockIdx.x, st_kt = 0;
+    auto set_src = [&](int t) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
 #pragma unroll
-    for (int i = 0; i < PIECES2; ++i) {
-        const int pc = wid * PIECES2 + i;
-        const bool is_a = pc < 32;
-        const int r = (is_a ? pc : pc - 32) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (r & 7);
-        src[i] = is_a ? p.A + (long)min(m0 + r, p.M - 1) * p.lda + c * 16
-                      : p.W + (long)min(n0 + r, p.N - 1) * p.ldw + c * 16;
-    }
+        for (int i = 0; i < PIECES2; ++i) {
+            const int pc = wid * PIECES2 + i;
+            const bool is_a = pc < 32;
+            const int r = (is_a ? pc : pc - 32) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            src[i] = is_a ? p.A + (long)min(m0 + r, p.M - 1) * p.lda + c * 16
+                          : p.W + (long)min(n0 + r, p.N - 1) * p.ldw + c * 16;
+        }
+    };
     char* const lds_wave = smem + wid * PIECES2 * 1024;
+    // stage the iterator's slab into ring slot `slot` and advance; returns false when the stream is exhausted
+    auto stage_next = [&](int slot) -> bool {
+        if (st_t >= nb) return false;
+        const long ko = (long)st_kt * ROW_BYTES;
+        char* dst = lds_wave + slot * SLAB2;
+#pragma unroll
+        for (int i = 0; i < PIECES2; ++i) glds16(src[i] + ko, dst + i * 1024);
+        if (++st_kt == KT) {
+            st_kt = 0;
+            st_t += gridDim.x;
+            if (st_t < nb) set_src(st_t);
+        }
+        return true;
+    };
 
     int foff[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
         foff[s] = (lane & 15) * ROW_BYTES + ((((s << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int KT = p.K / BK;
-    auto stage = [&](int kt, int buf) {
-        const long ko = (long)kt * ROW_BYTES;
-        char* dst = lds_wave + buf * SLAB2;
-#pragma unroll
-        for (int i = 0; i < PIECES2; ++i) glds16(src[i] + ko, dst + i * 1024);
-    };
-
     // fragment registers are double buffered: the ds_reads of the NEXT half step are issued before the
     // MFMAs of the current one, so LDS latency hides under the wave's own matrix work.
+    f32x4 acc[4][4];
     u32x4 af[2][4], wf[2][4];
     auto load_frags = [&](int buf, int s, int set) {
         const char* As = smem + buf * SLAB2 + wm * 64 * ROW_BYTES + foff[s];
@@ -277,49 +286,241 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x128_kernel(GemmArgs p) {
                             acc[mi][ni], 0, 0, 0);
         }
     };
-
-    stage(0, 0);
-    if (KT > 1) stage(1, 1);
-    if (KT > 2) stage(2, 2);
-    if (KT > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (KT > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    load_frags(0, 0, 0);
-    int buf = 0;
     // TOUCH(set): makes the compiler place its wait for that fragment set HERE (before newer ds_reads are
     // issued): hipcc cannot count lgkmcnt across the loop back-edge and would otherwise wait lgkmcnt(0) right
     // after issuing the next set, exposing one LDS latency per step.
 #define COGS_TOUCH(S)                                                                                        \
     asm volatile("" : "+v"(af[S][0]), "+v"(af[S][1]), "+v"(af[S][2]), "+v"(af[S][3]), "+v"(wf[S][0]), \
                  "+v"(wf[S][1]), "+v"(wf[S][2]), "+v"(wf[S][3]))
-    for (int kt = 0; kt < KT; ++kt) {
-        const int nbuf = buf == 2 ? 0 : buf + 1;
-        COGS_TOUCH(0);
-        load_frags(buf, 1, 1);
-        __builtin_amdgcn_s_setprio(1);
-        mma(0);
-        __builtin_amdgcn_s_setprio(0);
-        COGS_TOUCH(1);   // every read this wave made of slab kt is complete from here on
-        if (kt + 1 < KT) {
-            // slab kt+1 must have landed (own pieces: counted vmcnt; everyone's: barrier); after the barrier
-            // no wave reads slab kt any more, so its buffer is restaged with slab kt+3
-            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt + 3 < KT) stage(kt + 3, buf);
-            load_frags(nbuf, 0, 0);
+
+    if (st_t >= nb) return;
+    set_src(st_t);
+    // prologue: three slabs in flight, slab 0 landed
+    int staged = 0;   // slabs staged so far minus slabs consumed so far (0..3)
+    for (int i = 0; i < 3; ++i) staged += stage_next(i) ? 1 : 0;
+    if (staged == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (staged == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(0, 0, 0);
+    int buf = 0;
+
+    for (int t = blockIdx.x; t < nb; t += gridDim.x) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt) {
+            const int nbuf = buf == 2 ? 0 : buf + 1;
+            COGS_TOUCH(0);
+            load_frags(buf, 1, 1);
+            __builtin_amdgcn_s_setprio(1);
+            mma(0);
+            __builtin_amdgcn_s_setprio(0);
+            COGS_TOUCH(1);   // every read this wave made of the current slab is complete from here on
+            --staged;        // current slab consumed; `staged` slabs follow it in the ring
+            if (staged > 0) {
+                // the next slab must have landed (own pieces: counted vmcnt -- at most the 6 pieces of the slab
+                // after it may stay in flight; everyone's: barrier); after the barrier nobody reads the current
+                // slab any more, so its ring slot is restaged
+                if (staged > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                staged += stage_next(buf) ? 1 : 0;
+                load_frags(nbuf, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(1);
+            mma(1);
+            __builtin_amdgcn_s_setprio(0);
+            buf = nbuf;
         }
-        __builtin_amdgcn_s_setprio(1);
-        mma(1);
-        __builtin_amdgcn_s_setprio(0);
-        buf = nbuf;
+        epilogue_tile<T, EPI>(p.epi, m0 + wm * 64, n0 + wn * 64, p.M, p.N, lane, acc);
     }
 #undef COGS_TOUCH
+}
 
-    epilogue_tile<T, EPI>(p.epi, m0 + wm * 64, n0 + wn * 64, p.M, p.N, lane, acc);
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong variant (bf16): 256x256 output tile, 8 waves = two groups of 4 (one wave of each group
+// per SIMD), each wave 128x64. The K stream is cut into 32-wide K-tiles (64-byte LDS rows), 4-slot
+// ring (4 x 32 KiB). Every K-tile is two phases (upper / lower 64 rows of the wave's tile); a phase is
+//     L segment: ds_read the phase's fragments (8 or 4 x b128), issue 2 LDS-DMA pieces, lgkmcnt(0)
+//     --- s_barrier ---
+//     C segment: 16 MFMA
+//     --- s_barrier ---
+// and group 1 runs ONE BARRIER BEHIND group 0, so on every SIMD one wave is in its C segment while the
+// other is in its L segment: the matrix pipe never waits for LDS/DMA issue. Persistent over tiles with
+// a continuous K-tile stream (prefetch distance 3 K-tiles, counted vmcnt(8) once per K-tile).
+constexpr int BM3 = 256, BN3 = 256;
+constexpr int ROW3 = 64;                          // bytes per LDS row = 32 bf16
+constexpr int SLOT3 = (BM3 + BN3) * ROW3;         // 32 KiB per K-tile
+constexpr int RING3 = 4;
+
+__device__ __forceinline__ int swz3(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }   // [0,2,3,1]
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef bf16_t T;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2;          // 0: rows 0..127 of the tile, 1: rows 128..255; also the stagger group
+    const int wc = wid & 3;
+    const int nb = p.nbm * p.nbn;
+    const int KT = p.K / 32;
+
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int xcd = t & 7, q = nb >> 3, r = nb & 7;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+        const int per_group = GROUP_M * p.nbn;
+        const int first_m = (bid / per_group) * GROUP_M;
+        const int gsz = min(p.nbm - first_m, GROUP_M);
+        m0 = (first_m + (bid % per_group) % gsz) * BM3;
+        n0 = ((bid % per_group) / gsz) * BN3;
+    };
+
+    // staging: a K-tile is 32 pieces of 1 KiB (16 rows x 64 B); wave w owns pieces 4w..4w+3
+    // (pieces 0..15 = A rows, 16..31 = W rows); lane -> row lane>>2, LDS chunk lane&3, source chunk swizzled
+    const char* src[4];
+    int st_t = blockIdx.x, st_kt = 0;
+    auto set_src = [&](int t) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = wid * 4 + i;
+            const bool is_a = pc < 16;
+            const int r = (is_a ? pc : pc - 16) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ swz3(lane >> 2);
+            src[i] = is_a ? p.A + (long)min(m0 + r, p.M - 1) * p.lda + c * 16
+                          : p.W + (long)min(n0 + r, p.N - 1) * p.ldw + c * 16;
+        }
+    };
+    char* const lds_wave = smem + wid * 4096;
+    int st_slot = 0;
+    // issue pieces 2h, 2h+1 of the staging iterator's K-tile; after h == 1 the iterator advances
+    auto stage_half = [&](int h) {
+        if (st_t >= nb) return;
+        const long ko = (long)st_kt * ROW3;
+        char* dst = lds_wave + st_slot * SLOT3;
+        glds16(src[2 * h] + ko, dst + (2 * h) * 1024);
+        glds16(src[2 * h + 1] + ko, dst + (2 * h + 1) * 1024);
+        if (h == 1) {
+            st_slot = (st_slot + 1) & 3;
+            if (++st_kt == KT) {
+                st_kt = 0;
+                st_t += gridDim.x;
+                if (st_t < nb) set_src(st_t);
+            }
+        }
+    };
+
+    // fragment read offsets: row r = lane&15, k-chunk g = lane>>4
+    const int foff = (lane & 15) * ROW3 + (((lane >> 4) ^ swz3(lane & 15)) << 4);
+    const int a_off = (grp * 128) * ROW3 + foff;                 // + mh*64*ROW3 + mi*16*ROW3
+    const int w_off = BM3 * ROW3 + (wc * 64) * ROW3 + foff;      // + ni*16*ROW3
+
+    f32x4 acc[2][4][4];
+    u32x4 afr[4], wfr[4];
+
+    if (st_t >= nb) return;
+    set_src(st_t);
+    const int my_tiles = (nb - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    const int total = my_tiles * KT;          // K-tiles this workgroup consumes
+    // prologue: K-tiles 0..2 in flight (4 pieces each), K-tile 0 landed
+    {
+        int pre = total < 3 ? total : 3;
+        for (int i = 0; i < pre; ++i) { stage_half(0); stage_half(1); }
+        if (pre == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (pre == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+
+    int slot = 0;
+    int g = 0;   // index of the K-tile being consumed (0..total-1)
+    for (int t = blockIdx.x; t < nb; t += gridDim.x) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt, ++g) {
+            const char* base = smem + slot * SLOT3;
+            // ---- phase 0: L segment ----
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wfr[i] = *reinterpret_cast<const u32x4*>(base + w_off + i * 16 * ROW3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) afr[i] = *reinterpret_cast<const u32x4*>(base + a_off + i * 16 * ROW3);
+            // K-tile g+3 (pieces 0,1) -> ring slot of K-tile g-1: its last ds_reads (group 1, previous interval)
+            // were drained by that wave's lgkmcnt(0) BEFORE the barrier that opened this interval (WAR safe).
+            // (Measured: draining LDS reads before the barrier with prefetch distance 3 beats distance 2 with
+            // the wait behind the barrier by 3-4 %.)
+            stage_half(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(afr[0]), "+v"(afr[1]), "+v"(afr[2]), "+v"(afr[3]), "+v"(wfr[0]), "+v"(wfr[1]),
+                         "+v"(wfr[2]), "+v"(wfr[3]));
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 0: C segment ----
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[0][mi][ni], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1: L segment ----
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                afr[i] = *reinterpret_cast<const u32x4*>(base + a_off + 64 * ROW3 + i * 16 * ROW3);
+            stage_half(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(afr[0]), "+v"(afr[1]), "+v"(afr[2]), "+v"(afr[3]));
+            // K-tile g+1 must have landed before anyone reads it (interval after the next-but-one barrier for
+            // group 0, after the next barrier for group 1): both groups wait at the end of THIS interval --
+            // group 1 here (end of its L segment), group 0 at the end of its C segment below.
+            const int ahead = total - 1 - g;   // K-tiles after the current one
+            if (grp == 1) {
+                if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1: C segment ----
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[1][mi][ni], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("" ::: "memory");
+            if (grp == 0) {
+                if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            slot = (slot + 1) & 3;
+        }
+        // epilogue of this tile; it runs inside this group's next L interval, i.e. beside the other group's C
+        epilogue_tile<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0]);
+        epilogue_tile<T, EPI>(p.epi, m0 + grp * 128 + 64, n0 + wc * 64, p.M, p.N, lane, acc[1]);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
 }
 
 }  // namespace
@@ -346,8 +547,37 @@ void launch_big(hipStream_t st, const GemmArgs& p, int grid) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_256x128_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_tn_256x128_kernel<T, EPI>), dim3(grid), dim3(512), lds, st, p);
+    static const int env_wgs = getenv("COGS_GEMM_WGS") ? atoi(getenv("COGS_GEMM_WGS")) : PERSISTENT_WGS;
+    const int wgs = env_wgs <= 0 ? grid : (grid < env_wgs ? grid : env_wgs);   // 0 = one tile per workgroup
+    hipLaunchKernelGGL((gemm_tn_256x128_kernel<T, EPI>), dim3(wgs), dim3(512), lds, st, p);
 }
+template <int EPI>
+void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
+    const size_t lds = RING3 * SLOT3;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, p);
+}
+void dispatch_pp(hipStream_t st, const GemmArgs& p, int grid, int mask) {
+#define COGS_PP_CASE(E) case E: launch_pp<E>(st, p, grid); break;
+    switch (mask) {
+        COGS_PP_CASE(0)
+        COGS_PP_CASE(EPI_BIAS)
+        COGS_PP_CASE(EPI_RES)
+        COGS_PP_CASE(EPI_BIAS | EPI_RES)
+        COGS_PP_CASE(EPI_BIAS | EPI_ROPE)
+        COGS_PP_CASE(EPI_BIAS | EPI_GELU_TANH)
+        COGS_PP_CASE(EPI_BIAS | EPI_GELU_ERF)
+        COGS_PP_CASE(EPI_SWIGLU)
+        COGS_PP_CASE(EPI_F32OUT)
+        default: launch_pp<EPI_GENERIC>(st, p, grid); break;
+    }
+#undef COGS_PP_CASE
+}
+
 template <typename T>
 void dispatch(hipStream_t st, const GemmArgs& p, int grid, int mask, bool big) {
 #define COGS_EPI_CASE(E) \
@@ -383,6 +613,15 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     p.W = (const char*)g.W; p.ldw = g.ldw * es;
     p.M = g.M; p.N = g.N; p.K = g.K;
     static const bool env_small = getenv("COGS_GEMM_SMALL") != nullptr;
+    static const bool env_nopp = getenv("COGS_GEMM_NOPP") != nullptr;
+    const int n_pad = (g.N + BN3 - 1) / BN3 * BN3;
+    const bool pp_fits = n_pad * 100 <= g.N * 108;   // <= 8 % of the MFMAs spent on N padding
+    if (!env_nopp && !env_small && g.dtype == COGS_DT_BF16 && g.M >= 1024 && pp_fits && !g.force_small_tile) {
+        p.nbm = (g.M + BM3 - 1) / BM3;
+        p.nbn = (g.N + BN3 - 1) / BN3;
+        dispatch_pp(st, p, p.nbm * p.nbn, cogs_epi_mask(g));
+        return COGS_LAUNCH_CHECK();
+    }
     const bool big = g.M >= 512 && !g.force_small_tile && !env_small;
     p.nbm = (g.M + (big ? BM2 : BM) - 1) / (big ? BM2 : BM);
     p.nbn = (g.N + BN - 1) / BN;

@@ -75,6 +75,17 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& p, int m, int n, f32x4 
         st4_f<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
 }
 
+// raw storage of 4 consecutive elements (converted to fp32 only when used)
+template <typename T> struct RawVec;
+template <> struct RawVec<bf16_t> {
+    typedef u32x2 type;
+    static __device__ __forceinline__ f32x4 to_f32(u32x2 w) { return f32x4{bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])}; }
+};
+template <> struct RawVec<float> {
+    typedef f32x4 type;
+    static __device__ __forceinline__ f32x4 to_f32(f32x4 w) { return w; }
+};
+
 // Epilogue of one wave's 64x64 tile held as acc[mi][ni] (lane: row mb + 16 mi + (lane&15), columns
 // nb + 16 ni + 4 (lane>>4) .. +3). Loads first, then math + stores.
 template <typename T, int EPI>
@@ -95,75 +106,82 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
         }
         return;
     } else {
-        // ---- phase 1: every load of the tile (clamped addresses keep the loads unconditional) ----
+        // Two half tiles (mi pairs): per half, phase 1 issues every load (residual kept RAW, i.e. 2 VGPRs per
+        // fragment for bf16; clamped addresses keep the loads unconditional), phase 2 does math + stores.
+        // Batching per half caps the live registers (16 raw residual + 32 rotary) so hipcc does not fall back
+        // to load->use round trips when the persistent loop keeps next-tile fragments live.
+        using raw_t = typename RawVec<T>::type;
         f32x4 bias_v[4];
-        f32x4 res_v[4][4];
-        f32x2 cs[4][4], sn[4][4];
-        int mm[4], nn[4];
+        int nn[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            mm[i] = min(mrow + i * 16, M - 1);
-            nn[i] = min(ncol + i * 16, N - 4);
-        }
+        for (int i = 0; i < 4; ++i) nn[i] = min(ncol + i * 16, N - 4);
         if constexpr ((EPI & EPI_BIAS) != 0) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) bias_v[ni] = ld4_f<T>(reinterpret_cast<const T*>(p.bias) + nn[ni]);
         }
-        if constexpr ((EPI & EPI_RES) != 0) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+        for (int half = 0; half < 2; ++half) {
+            raw_t res_raw[2][4];
+            f32x2 cs[2][4], sn[2][4];
+            int mm[2];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    res_v[mi][ni] = ld4_f<T>(reinterpret_cast<const T*>(p.R) + (long)mm[mi] * p.ldr + nn[ni]);
-        }
-        if constexpr ((EPI & EPI_ROPE) != 0) {
+            for (int i = 0; i < 2; ++i) mm[i] = min(mrow + (2 * half + i) * 16, M - 1);
+            if constexpr ((EPI & EPI_RES) != 0) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        res_raw[i][ni] = *reinterpret_cast<const raw_t*>(reinterpret_cast<const T*>(p.R) + (long)mm[i] * p.ldr + nn[ni]);
+            }
+            if constexpr ((EPI & EPI_ROPE) != 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const int pi = (nn[ni] % p.head_dim) >> 1;
+                        cs[i][ni] = *reinterpret_cast<const f32x2*>(p.rope_cos + (long)mm[i] * p.rope_pairs + pi);
+                        sn[i][ni] = *reinterpret_cast<const f32x2*>(p.rope_sin + (long)mm[i] * p.rope_pairs + pi);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int mi = 2 * half + i;
+                const int m = mrow + mi * 16;
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    const int pi = (nn[ni] % p.head_dim) >> 1;
-                    cs[mi][ni] = *reinterpret_cast<const f32x2*>(p.rope_cos + (long)mm[mi] * p.rope_pairs + pi);
-                    sn[mi][ni] = *reinterpret_cast<const f32x2*>(p.rope_sin + (long)mm[mi] * p.rope_pairs + pi);
-                }
-        }
-        // ---- phase 2: arithmetic + stores ----
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = mrow + mi * 16;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = ncol + ni * 16;
-                f32x4 v = acc[mi][ni];
-                if constexpr ((EPI & EPI_BIAS) != 0) v += bias_v[ni];
-                if constexpr ((EPI & EPI_ROPE) != 0) {
-                    if (n < p.rope_cols) {
-                        const f32x2 c = cs[mi][ni], s = sn[mi][ni];
-                        f32x4 r;
-                        r[0] = v[0] * c[0] - v[1] * s[0];
-                        r[1] = v[1] * c[0] + v[0] * s[0];
-                        r[2] = v[2] * c[1] - v[3] * s[1];
-                        r[3] = v[3] * c[1] + v[2] * s[1];
-                        v = r;
+                    const int n = ncol + ni * 16;
+                    f32x4 v = acc[mi][ni];
+                    if constexpr ((EPI & EPI_BIAS) != 0) v += bias_v[ni];
+                    if constexpr ((EPI & EPI_ROPE) != 0) {
+                        if (n < p.rope_cols) {
+                            const f32x2 c = cs[i][ni], sx = sn[i][ni];
+                            f32x4 r;
+                            r[0] = v[0] * c[0] - v[1] * sx[0];
+                            r[1] = v[1] * c[0] + v[0] * sx[0];
+                            r[2] = v[2] * c[1] - v[3] * sx[1];
+                            r[3] = v[3] * c[1] + v[2] * sx[1];
+                            v = r;
+                        }
                     }
-                }
-                if constexpr ((EPI & EPI_GELU_TANH) != 0) {
+                    if constexpr ((EPI & EPI_GELU_TANH) != 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-                }
-                if constexpr ((EPI & EPI_GELU_ERF) != 0) {
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                    }
+                    if constexpr ((EPI & EPI_GELU_ERF) != 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
-                }
-                if constexpr ((EPI & EPI_RES) != 0) v += res_v[mi][ni];
-                if (m < M && n < N) {
-                    if constexpr ((EPI & EPI_SWIGLU) != 0) {
-                        T* cp = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + (n >> 1);
-                        st_f<T>(cp, silu_f(v[0]) * v[1]);
-                        st_f<T>(cp + 1, silu_f(v[2]) * v[3]);
-                    } else if constexpr ((EPI & EPI_F32OUT) != 0) {
-                        st4_f<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
-                    } else {
-                        st4_f<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                    }
+                    if constexpr ((EPI & EPI_RES) != 0) v += RawVec<T>::to_f32(res_raw[i][ni]);
+                    if (m < M && n < N) {
+                        if constexpr ((EPI & EPI_SWIGLU) != 0) {
+                            T* cp = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + (n >> 1);
+                            st_f<T>(cp, silu_f(v[0]) * v[1]);
+                            st_f<T>(cp + 1, silu_f(v[2]) * v[3]);
+                        } else if constexpr ((EPI & EPI_F32OUT) != 0) {
+                            st4_f<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
+                        } else {
+                            st4_f<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
+                        }
                     }
                 }
             }
