@@ -456,9 +456,11 @@ cogs_status cogs_llm_load(cogs_handle h, const cogs_llm_weights* w) {
 }
 
 static int llm_nsplit(int ctx) {
-    int n = (ctx + 1023) / 1024;
+    // decode attention: (kv heads x splits) workgroups should cover the 256 CUs about twice; each split
+    // keeps at least 4 key tiles (256 keys)
+    int n = (ctx + 255) / 256;
     if (n < 1) n = 1;
-    if (n > 32) n = 32;
+    if (n > 128) n = 128;
     return n;
 }
 
@@ -507,12 +509,14 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < w.layers; ++l) {
         const cogs_llm_layer& L = h->llm_layers[l];
-        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.in_ln, S, H, w.rms_eps)); }
+        const bool fuse_norm = (S == 1);   // single-token decode: RMSNorm runs inside the GEMV prologue
+        if (!fuse_norm) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.in_ln, S, H, w.rms_eps)); }
         {
             CogsGemm g; g.dtype = dt;
-            g.A = ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = qd;
+            g.A = fuse_norm ? x : ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = qd;
             g.bias = L.qkv_b; g.M = S; g.N = qd; g.K = H;
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = qd_q + kvd; g.head_dim = hd;
+            if (fuse_norm) { g.rms_gamma = L.in_ln; g.rms_eps = w.rms_eps; }
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         const char* kp = (const char*)qkv + (size_t)qd_q * es;
@@ -521,8 +525,8 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
         if (kv) {
             char* kc = (char*)kv->k + ((size_t)l * kv->max_len) * kvd * es;
             char* vc = (char*)kv->v + ((size_t)l * kv->max_len) * kvd * es;
-            { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_copy_cols(st, dt, kp, qd, kc + (size_t)pos0 * kvd * es, kvd, S, kvd)); }
-            { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_copy_cols(st, dt, vp, qd, vc + (size_t)pos0 * kvd * es, kvd, S, kvd)); }
+            { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_kv_append(st, dt, kp, vp, qd, kc + (size_t)pos0 * kvd * es,
+                                                                vc + (size_t)pos0 * kvd * es, kvd, S, kvd)); }
             kp = kc; vp = vc; ldkv = kvd;
         }
         {
@@ -542,11 +546,12 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
             g.residual = x; g.ldr = H; g.M = S; g.N = H; g.K = qd_q;
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
-        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.post_ln, S, H, w.rms_eps)); }
+        if (!fuse_norm) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.post_ln, S, H, w.rms_eps)); }
         {
             CogsGemm g; g.dtype = dt;
-            g.A = ln; g.lda = H; g.W = L.gu_w; g.ldw = H; g.C = act; g.ldc = w.inter;
+            g.A = fuse_norm ? x : ln; g.lda = H; g.W = L.gu_w; g.ldw = H; g.C = act; g.ldc = w.inter;
             g.M = S; g.N = 2 * w.inter; g.K = H; g.act = COGS_ACT_SWIGLU;
+            if (fuse_norm) { g.rms_gamma = L.post_ln; g.rms_eps = w.rms_eps; }
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         {
@@ -569,9 +574,9 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
     } else if (last_logits) {
-        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, (char*)x + (size_t)(S - 1) * H * es, ln, w.final_norm, 1, H, w.rms_eps)); }
         CogsGemm g; g.dtype = dt;
-        g.A = ln; g.lda = H; g.W = w.lm_head; g.ldw = H; g.C = last_logits; g.ldc = w.vocab;
+        g.rms_gamma = w.final_norm; g.rms_eps = w.rms_eps;   // final RMSNorm fused into the lm_head GEMV
+        g.A = (char*)x + (size_t)(S - 1) * H * es; g.lda = H; g.W = w.lm_head; g.ldw = H; g.C = last_logits; g.ldc = w.vocab;
         g.M = 1; g.N = w.vocab; g.K = H; g.out_f32 = 1;
         { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
     }

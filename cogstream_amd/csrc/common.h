@@ -121,12 +121,13 @@ __device__ __forceinline__ float wave_min(float v) {
 
 // activations (fp32)
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))  (ACT2FN["gelu_pytorch_tanh"])
-    // = x * sigmoid(2u): one v_exp + one v_rcp instead of libm tanhf (~50 instructions); the fp32 error
-    // (~1e-7 relative) is far below the bf16 output rounding
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    return x * __frcp_rn(1.0f + __expf(-2.0f * u));
+    // 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715x^3)   (ACT2FN["gelu_pytorch_tanh"])
+    //   = x * sigmoid(2u) = x / (1 + 2^(x*(a + b*x^2))),  a = -2*sqrt(2/pi)*log2(e), b = a*0.044715
+    // 7 VALU incl. one v_exp_f32 and one v_rcp_f32 (1 ulp) instead of libm tanhf (~50 instructions); the
+    // fp32 error (~2e-7 relative) is far below the bf16 output rounding and inside the fp32-mode tolerance
+    const float a = -2.3022082f, b = -0.10294324f;
+    const float t = x * fmaf(b, x * x, a);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));

@@ -606,6 +606,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     if (g.K % BK != 0 || g.N % 4 != 0) return COGS_E_INVALID;
     if ((g.lda * es) % 16 != 0 || (g.ldw * es) % 16 != 0) return COGS_E_INVALID;
     if (g.M == 1) return cogs_k_gemv(st, g);
+    if (g.rms_gamma) return COGS_E_UNSUPPORTED;   // fused RMSNorm exists for the single-token GEMV only
     GemmArgs p;
     const int rc = cogs_fill_epi(g, &p.epi);
     if (rc != COGS_OK) return rc;

@@ -25,6 +25,8 @@ struct CogsGemm {
     int rope_cols = 0;
     int head_dim = 0;
     int force_small_tile = 0;                // testing: always use the 128x128 kernel
+    const void* rms_gamma = nullptr;         // M == 1 only: RMS-normalise A on the fly with this weight
+    float rms_eps = 0.f;
 };
 int cogs_k_gemm(hipStream_t st, const CogsGemm& g);
 
@@ -89,6 +91,9 @@ int cogs_k_kmeans_update(hipStream_t st, int dtype, const void* feats, const flo
 int cogs_k_kmeans_update_blocks(long PD);
 
 // LLM helpers
+// append S rows of K and V (adjacent column blocks of the fused qkv buffer) to the two caches in one launch
+int cogs_k_kv_append(hipStream_t st, int dtype, const void* k_src, const void* v_src, long ld_src, void* k_dst,
+                     void* v_dst, long ld_dst, int rows, int cols);
 int cogs_k_copy_cols(hipStream_t st, int dtype, const void* src, long ld_src, void* dst, long ld_dst, int rows, int cols);
 int cogs_k_argmax(hipStream_t st, const float* logits, int n, int64_t* out, float* ws);
 // HF logits processors on one fp32 row: repetition penalty over `prev` (gather-then-scatter, so

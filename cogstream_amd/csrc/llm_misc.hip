@@ -20,6 +20,21 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const char* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void kv_append_kernel(const char* __restrict__ ks, const char* __restrict__ vs,
+                                                        long ld_src, char* __restrict__ kd, char* __restrict__ vd,
+                                                        long ld_dst, int rows, int chunks) {
+    const long total = (long)rows * chunks * 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int which = (int)(i & 1);
+        const long j = i >> 1;
+        const long r = j / chunks;
+        const int c = (int)(j % chunks);
+        const char* s = (which ? vs : ks) + r * ld_src + c * 16;
+        char* d = (which ? vd : kd) + r * ld_dst + c * 16;
+        *reinterpret_cast<u32x4*>(d) = *reinterpret_cast<const u32x4*>(s);
+    }
+}
+
 // first-maximum argmax, two stages
 constexpr int AM_BLOCKS = 64;
 __global__ __launch_bounds__(256) void argmax_part_kernel(const float* __restrict__ x, int n, float* __restrict__ ws) {
@@ -133,6 +148,19 @@ int cogs_k_copy_cols(hipStream_t st, int dtype, const void* src, long ld_src, vo
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)g), dim3(256), 0, st, (const char*)src, ld_src * es, (char*)dst,
                        ld_dst * es, rows, chunks);
+    return COGS_LAUNCH_CHECK();
+}
+
+int cogs_k_kv_append(hipStream_t st, int dtype, const void* k_src, const void* v_src, long ld_src, void* k_dst,
+                     void* v_dst, long ld_dst, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return COGS_OK;
+    const int es = dtype == COGS_DT_BF16 ? 2 : 4;
+    if ((cols * es) % 16 || (ld_src * es) % 16 || (ld_dst * es) % 16) return COGS_E_INVALID;
+    const int chunks = cols * es / 16;
+    long g = ((long)rows * chunks * 2 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(kv_append_kernel, dim3((unsigned)g), dim3(256), 0, st, (const char*)k_src, (const char*)v_src,
+                       ld_src * es, (char*)k_dst, (char*)v_dst, ld_dst * es, rows, chunks);
     return COGS_LAUNCH_CHECK();
 }
 

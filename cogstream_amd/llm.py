@@ -77,26 +77,48 @@ class Qwen2Engine:
         S = embeds.shape[0]
         if cache is None:
             cache = self.new_cache(S + max_new_tokens)
+        pos_start = cache.len + S
         res = self.forward(embeds, cache)
         allowed = (torch.tensor(list(allowed_ids), dtype=torch.int32, device=self.device) if allowed_ids is not None else None)
-        seen: List[int] = [int(t) for t in prompt_ids.reshape(-1).tolist()] if prompt_ids is not None else []
-        out: List[int] = []
         eos = set(int(e) for e in eos_token_id)
+        # token ids stay on the device: the greedy id feeds the next embedding gather and the repetition-penalty
+        # history without a host round trip; the host only looks at them every `check_every` steps (EOS test).
+        n_prompt = int(prompt_ids.numel()) if prompt_ids is not None else 0
+        seen = torch.empty(n_prompt + max_new_tokens, dtype=torch.int64, device=self.device)
+        if n_prompt:
+            seen[:n_prompt] = prompt_ids.reshape(-1).to(self.device)
+        toks = torch.empty(max_new_tokens, dtype=torch.int64, device=self.device)
+        n_seen, produced = n_prompt, 0
+        check_every = 1 if do_sample else 8
+        need_proc = repetition_penalty != 1.0 or allowed is not None or (do_sample and temperature != 1.0)
+        stop_at = None
         for step in range(max_new_tokens):
             logits = res["logits"]
-            prev = torch.tensor(seen, dtype=torch.int64, device=self.device) if (seen and repetition_penalty != 1.0) else None
-            if prev is not None or allowed is not None or (do_sample and temperature != 1.0):
+            if need_proc:
+                prev = seen[:n_seen] if (n_seen and repetition_penalty != 1.0) else None
                 ops.logits_process(logits, prev, repetition_penalty, allowed, temperature if do_sample else 1.0)
             if do_sample:
-                tok = self._sample(logits, top_k, top_p, generator)
+                tok_dev = torch.tensor([self._sample(logits, top_k, top_p, generator)], dtype=torch.int64, device=self.device)
             else:
-                tok = int(ops.argmax(logits))
-            out.append(tok)
-            seen.append(tok)
-            if tok in eos and not ignore_eos:
-                break
-            if step + 1 < max_new_tokens:
-                res = self.forward(self.embed_tokens(torch.tensor([tok])), cache)
+                tok_dev = ops.argmax(logits)
+            toks[step:step + 1].copy_(tok_dev)
+            seen[n_seen:n_seen + 1].copy_(tok_dev)
+            n_seen += 1
+            produced += 1
+            last = step + 1 == max_new_tokens
+            if eos and not ignore_eos and ((step + 1) % check_every == 0 or last):
+                host = toks[:produced].tolist()
+                hit = next((i for i, t in enumerate(host) if t in eos), None)
+                if hit is not None:
+                    stop_at = hit + 1
+                    break
+            if not last:
+                res = self.forward(self.embed_tokens(tok_dev), cache)
+        out = toks[:produced].tolist()
+        if stop_at is not None:
+            out = out[:stop_at]
+            # forwards issued past the EOS only wrote KV rows that are dropped again here
+            cache.reset(min(cache.len, pos_start + stop_at - 1))
         return out
 
     def _sample(self, logits: torch.Tensor, top_k: int, top_p: float, generator) -> int:
