@@ -362,32 +362,51 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
     }
 }
 
-// combine the key-split partials: one wave per (query row, head)
-__global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ part_o,
-                                                          const float* __restrict__ part_ml, int nsplit, int q_len,
-                                                          int hq, int HD, bf16_t* __restrict__ O, long ldo) {
-    const int lane = threadIdx.x;
+// combine the key-split partials: one 256-thread block per (query row, head). The split weights are computed
+// once (thread s owns split s), then the [nsplit, HD] partial rows are summed with independent loads:
+// 256/HDP split-groups run in parallel and meet in LDS.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o,
+                                                           const float* __restrict__ part_ml, int nsplit, int q_len,
+                                                           int hq, int HD, bf16_t* __restrict__ O, long ldo) {
+    __shared__ float w_sh[128];
+    __shared__ float red[256];
+    __shared__ float l_sh[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int q = blockIdx.x, h = blockIdx.y;
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[(((long)s * q_len + q) * hq + h) * 2]);
-    float L = 0.f;
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < nsplit; ++s) {
-        const long slot = ((long)s * q_len + q) * hq + h;
-        const float m = part_ml[slot * 2];
-        const float w = (m == -INFINITY) ? 0.f : exp2f(m - M);
-        L += part_ml[slot * 2 + 1] * w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int d = lane + 64 * e;
-            if (d < HD) o[e] += part_o[slot * HD + d] * w;
-        }
+    // weights: w_s = 2^(m_s - M), L = sum l_s w_s   (nsplit <= 128)
+    float m = -INFINITY, l = 0.f;
+    if (tid < nsplit) {
+        const long slot = ((long)tid * q_len + q) * hq + h;
+        m = part_ml[slot * 2];
+        l = part_ml[slot * 2 + 1];
     }
-    const float inv = L > 0.f ? 1.f / L : 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int d = lane + 64 * e;
-        if (d < HD) O[(long)q * ldo + h * HD + d] = f2bf(o[e] * inv);
+    float M = wave_max(m);
+    if (lane == 0) l_sh[wid] = M;
+    __syncthreads();
+    M = fmaxf(fmaxf(l_sh[0], l_sh[1]), fmaxf(l_sh[2], l_sh[3]));
+    const float w = (m == -INFINITY) ? 0.f : exp2f(m - M);
+    if (tid < 128) w_sh[tid] = w;
+    float lw = wave_sum(l * w);
+    __syncthreads();
+    if (lane == 0) l_sh[wid] = lw;
+    __syncthreads();
+    const float L = l_sh[0] + l_sh[1] + l_sh[2] + l_sh[3];
+    // o[d] = sum_s w_s part_o[s][d]: thread (d, group) strides the splits by the number of groups
+    const int HDP = HD <= 64 ? 64 : (HD <= 128 ? 128 : 256);
+    const int groups = 256 / HDP;
+    const int d = tid % HDP, grp = tid / HDP;
+    float acc = 0.f;
+    if (d < HD) {
+#pragma unroll 4
+        for (int s = grp; s < nsplit; s += groups)
+            acc += part_o[(((long)s * q_len + q) * hq + h) * HD + d] * w_sh[s];
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < HDP && tid < HD) {
+        float o = 0.f;
+        for (int g2 = 0; g2 < groups; ++g2) o += red[g2 * HDP + tid];
+        O[(long)q * ldo + h * HD + tid] = f2bf(L > 0.f ? o / L : 0.f);
     }
 }
 
@@ -482,7 +501,7 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
         int qtiles = (max_len + 127) / 128;
         int gy = a.hq;
         if (a.nsplit > 1) {
-            if (a.cu_seqlens || a.row_lo) return COGS_E_UNSUPPORTED;
+            if (a.cu_seqlens || a.row_lo || a.nsplit > 128) return COGS_E_UNSUPPORTED;
             const size_t need = (size_t)a.nsplit * a.q_len * a.hq * (a.head_dim + 2) * sizeof(float);
             if (!a.ws || a.ws_bytes < need) return COGS_E_WORKSPACE;
             p.nsplit = a.nsplit;
@@ -496,7 +515,7 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
         else
             hipLaunchKernelGGL(attn_fwd_bf16_kernel<128>, grid, dim3(256), 0, st, p);
         if (p.nsplit > 1)
-            hipLaunchKernelGGL(attn_combine_kernel, dim3(a.q_len, a.hq), dim3(64), 0, st, p.part_o, p.part_ml, p.nsplit,
+            hipLaunchKernelGGL(attn_combine_kernel, dim3(a.q_len, a.hq), dim3(256), 0, st, p.part_o, p.part_ml, p.nsplit,
                                a.q_len, a.hq, a.head_dim, (bf16_t*)a.O, a.ldo);
         return COGS_LAUNCH_CHECK();
     }
