@@ -149,3 +149,22 @@ def test_end_to_end_bf16_block_diag_runs(dev):
                             max_new_tokens=4)
     assert ids.shape == (1, 4) or ids.shape[1] <= 4
     assert len(model.last_debug["assign"]) == 150 and int(model.last_debug["compression_mask"].sum()) > 150
+
+
+def test_multi_turn_session_runs(dev):
+    """cfg4-style streaming session on the tiny model: 3 segments, growing history, retrieval from turn 2 on"""
+    from cogstream_amd import processing as pr
+    from cogstream_amd.answer_generate import run_session, shard_videos
+    from toy_tokenizer import ToyTokenizer
+    model = _tiny_model(dev, torch.bfloat16, 0)
+    tok = ToyTokenizer()
+    proc = pr.CogStreamProcessor(tok)
+    segs = []
+    for i in range(3):
+        fr, ts = pr.synthetic_clip(4, 56, 56, kind="drift", clip_idx=i)
+        segs.append({"video": fr, "timestamps": [t + 4 * i for t in ts], "questions": [f"What happens in part {i}?"] + (["And then?"] if i == 1 else [])})
+    recs = run_session(model, proc, segs, max_new_tokens=4, do_sample=False)
+    assert [r["qa_id"] for r in recs] == [0, 1, 2, 3]
+    assert recs[0]["predicted_coi"] == [] and len(recs[3]["predicted_coi"]) == 3
+    assert all(isinstance(r["prediction"], str) for r in recs)
+    assert shard_videos(10, 1, 4) == [1, 5, 9] and shard_videos(10, 3, 4) == [3, 7, 1]
