@@ -154,9 +154,17 @@ def main() -> None:
         gflops = vit_gemm_flops(n_loc, m_proj, vcfg, lcfg.hidden_size)
         gemm_ms, gemm_n = float(ms[0]), int(cnt[0])
         ach = gflops / (gemm_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_tn_kernel<bf16> (all encoder+projector GEMM launches)",
+        # HBM-side traffic per GEMM launch: PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 read
+        # correction) collected with tools/collect_profiles.sh and committed under profiles/
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_b_gemm_traffic.json")
+        if world == 1 and T == 64 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")
+        out["roofline"] = {"bound": "mfma",
+                           "kernel": "bf16 MFMA GEMM (gemm_tn_pp_kernel<*> + gemm_tn_256x128_kernel<*>, every "
+                                     "encoder+projector GEMM launch of one step)",
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                            "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                            "flop_per_launch": gflops / max(gemm_n, 1)}
         attn_ms = float(ms[1])
