@@ -573,6 +573,7 @@ void dispatch_pp(hipStream_t st, const GemmArgs& p, int grid, int mask) {
         COGS_PP_CASE(EPI_BIAS | EPI_GELU_ERF)
         COGS_PP_CASE(EPI_SWIGLU)
         COGS_PP_CASE(EPI_F32OUT)
+        COGS_PP_CASE(EPI_NOSTORE)
         default: launch_pp<EPI_GENERIC>(st, p, grid); break;
     }
 #undef COGS_PP_CASE
@@ -620,7 +621,8 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     if (!env_nopp && !env_small && g.dtype == COGS_DT_BF16 && g.M >= 1024 && pp_fits && !g.force_small_tile) {
         p.nbm = (g.M + BM3 - 1) / BM3;
         p.nbn = (g.N + BN3 - 1) / BN3;
-        dispatch_pp(st, p, p.nbm * p.nbn, cogs_epi_mask(g));
+        static const bool env_nostore = getenv("COGS_GEMM_NOSTORE") != nullptr;
+        dispatch_pp(st, p, p.nbm * p.nbn, env_nostore ? EPI_NOSTORE : cogs_epi_mask(g));
         return COGS_LAUNCH_CHECK();
     }
     const bool big = g.M >= 512 && !g.force_small_tile && !env_small;
