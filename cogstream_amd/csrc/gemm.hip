@@ -443,6 +443,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
+    // vmcnt counts loads, LDS-DMA AND stores in issue order. The 16 stores of a tile epilogue are NEWER than the
+    // DMA pieces the next two K-tile waits are about, so those waits may leave them in flight (vmcnt(8+16));
+    // with a plain vmcnt(8) every tile boundary stalls for the full write latency. The count is exact only for
+    // interior tiles on the wide epilogue path (16 unpredicated store instructions); anything else keeps the
+    // conservative count. `epi_stores` is what the previous tile's epilogue left in flight.
+    // (A 256x128 ping-pong variant for N = 1152 was measured 10-15 % slower than the ring kernel: 64x64 per
+    // wave makes the L segment -- 8 reads + 3 DMA pieces -- too heavy for 16 MFMAs.)
+    constexpr bool WIDE_EPI = (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0;
+    int epi_stores = 0;
+    auto wait_next_ktile = [&](int ahead, int kt) {
+        const bool relaxed = epi_stores == 16 && kt < 2;
+        if (ahead >= 3) { if (relaxed) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else if (ahead == 2) { if (relaxed) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else { if (relaxed) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    };
+
     int slot = 0;
     int g = 0;   // index of the K-tile being consumed (0..total-1)
     for (int t = blockIdx.x; t < nb; t += gridDim.x) {
@@ -492,11 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
             // group 0, after the next barrier for group 1): both groups wait at the end of THIS interval --
             // group 1 here (end of its L segment), group 0 at the end of its C segment below.
             const int ahead = total - 1 - g;   // K-tiles after the current one
-            if (grp == 1) {
-                if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (grp == 1) wait_next_ktile(ahead, kt);
             __builtin_amdgcn_s_barrier();
             // ---- phase 1: C segment ----
             __builtin_amdgcn_s_setprio(1);
@@ -508,17 +520,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
                         __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[1][mi][ni], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             asm volatile("" ::: "memory");
-            if (grp == 0) {
-                if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (grp == 0) wait_next_ktile(ahead, kt);
             __builtin_amdgcn_s_barrier();
             slot = (slot + 1) & 3;
         }
         // epilogue of this tile; it runs inside this group's next L interval, i.e. beside the other group's C
         epilogue_tile<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0]);
         epilogue_tile<T, EPI>(p.epi, m0 + grp * 128 + 64, n0 + wc * 64, p.M, p.N, lane, acc[1]);
+        epi_stores = (WIDE_EPI && (p.N & 31) == 0 && m0 + BM3 <= p.M && n0 + BN3 <= p.N) ? 16 : 0;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
 }
