@@ -305,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x128_kernel(GemmArgs p) {
     asm volatile("" ::: "memory");
     load_frags(0, 0, 0);
     int buf = 0;
+    int epi_stores = 0;   // store instructions the previous tile's epilogue left in flight
 
     for (int t = blockIdx.x; t < nb; t += gridDim.x) {
         int m0, n0;
@@ -326,8 +327,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x128_kernel(GemmArgs p) {
                 // the next slab must have landed (own pieces: counted vmcnt -- at most the 6 pieces of the slab
                 // after it may stay in flight; everyone's: barrier); after the barrier nobody reads the current
                 // slab any more, so its ring slot is restaged
-                if (staged > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the 8 stores of the previous tile's (wide, interior) epilogue are newer than the pieces this wait is
+                // about for the first two slabs of a tile: leave them in flight (see the ping-pong kernel)
+                const bool relaxed = epi_stores == 8 && kt < 2;
+                if (staged > 1) { if (relaxed) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+                else { if (relaxed) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 staged += stage_next(buf) ? 1 : 0;
@@ -339,6 +343,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x128_kernel(GemmArgs p) {
             buf = nbuf;
         }
         epilogue_tile<T, EPI>(p.epi, m0 + wm * 64, n0 + wn * 64, p.M, p.N, lane, acc);
+        epi_stores = (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0 &&
+                      (p.N & 31) == 0 && m0 + BM2 <= p.M && n0 + BN <= p.N) ? 8 : 0;
     }
 #undef COGS_TOUCH
 }
@@ -626,7 +632,8 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     static const bool env_small = getenv("COGS_GEMM_SMALL") != nullptr;
     static const bool env_nopp = getenv("COGS_GEMM_NOPP") != nullptr;
     const int n_pad = (g.N + BN3 - 1) / BN3 * BN3;
-    const bool pp_fits = n_pad * 100 <= g.N * 108;   // <= 8 % of the MFMAs spent on N padding
+    static const int env_waste = getenv("COGS_GEMM_PPWASTE") ? atoi(getenv("COGS_GEMM_PPWASTE")) : 112;
+    const bool pp_fits = n_pad * 100 <= g.N * env_waste;   // default: <= 12 % of the MFMAs spent on N padding (N = 1152 -> 1280 measured faster than the 256x128 ring kernel)
     if (!env_nopp && !env_small && g.dtype == COGS_DT_BF16 && g.M >= 1024 && pp_fits && !g.force_small_tile) {
         p.nbm = (g.M + BM3 - 1) / BM3;
         p.nbn = (g.N + BN3 - 1) / BN3;
