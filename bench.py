@@ -140,16 +140,17 @@ def main() -> None:
                    "parallelism": f"frames sharded over {world} GPU(s) + all-gather" if world > 1 else "single GPU"},
     }
 
+    # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events around every launch ----
+    # every rank runs this pass (it contains the all-gather); rank 0 reports its own kernels
+    h = enc.handle
+    ms = (C.c_float * 4)()
+    cnt = (C.c_int * 4)()
+    barrier()
+    L.check(L.lib.cogs_profile_begin(h.h))
+    tok = enc(pix, grid_loc, merge)
+    proj(gather_tokens(tok, (T, gh, gw), 2, world))
+    L.check(L.lib.cogs_profile_end(h.h, L.current_stream(), ms, cnt))
     if rank == 0:
-        # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events around every launch ----
-        h = enc.handle
-        ms = (C.c_float * 4)()
-        cnt = (C.c_int * 4)()
-        torch.cuda.synchronize()
-        L.check(L.lib.cogs_profile_begin(h.h))
-        tok = enc(pix, grid_loc, merge)
-        proj(gather_tokens(tok, (T, gh, gw), 2, world))
-        L.check(L.lib.cogs_profile_end(h.h, L.current_stream(), ms, cnt))
         n_loc, m_proj = t_loc * per_frame, (m_tokens if world > 1 else t_loc * P)
         gflops = vit_gemm_flops(n_loc, m_proj, vcfg, lcfg.hidden_size)
         gemm_ms, gemm_n = float(ms[0]), int(cnt[0])
