@@ -86,7 +86,9 @@ def main() -> None:
 
     # ---- synthetic clip -> pixel_values (host preprocessing is outside the timed region) ----
     frames, timestamps = processing.synthetic_clip(T, kind=args.clip)
+    t0 = time.perf_counter()
     feats = processing.preprocess_videos([frames], merge_size=2)
+    t_host_pre = time.perf_counter() - t0
     t, gh, gw = (int(v) for v in feats["grid_sizes"][0])
     per_frame = gh * gw
     P = per_frame // 4
@@ -214,6 +216,24 @@ def main() -> None:
         out["e2e_s"] = round(ms_per_step * 1e-3 + t_gen, 4)
         del eng, cache
         torch.cuda.empty_cache()
+
+    # ---- GPU pre-processing of the same clip (uint8 frames -> pixel_values) ----
+    if rank == 0 and world == 1:
+        from cogstream_amd.preprocess_gpu import preprocess_videos_gpu
+        t0 = time.perf_counter()
+        dframes = torch.from_numpy(frames).to(dev)
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t0) * 1e3
+        got = preprocess_videos_gpu([dframes])
+        same = bool(torch.equal(got["pixel_values"], pix))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            preprocess_videos_gpu([dframes])
+        torch.cuda.synchronize()
+        out["preprocess"] = {"gpu_ms": round((time.perf_counter() - t0) / 5 * 1e3, 3), "h2d_ms": round(h2d_ms, 3),
+                             "host_pil_ms": round(t_host_pre * 1e3, 1), "equal_to_host_path": same}
+        del dframes, got
 
     # ---- CPU baseline: the oracle on host cores, bounded sample (rank 0, N = 1) ----
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -228,6 +228,21 @@ cogs_status cogs_pack_rows(cogs_stream stream, int in_dtype, int out_dtype, cons
     return cogs_k_pack_rows((hipStream_t)stream, in_dtype, out_dtype, in, ld_in, out, ld_out, rows, cols_in, cols_out);
 }
 
+cogs_status cogs_preprocess_workspace_bytes(int T, int H, int tw, size_t* bytes) {
+    if (!bytes || T <= 0 || H <= 0 || tw <= 0) return COGS_E_INVALID;
+    *bytes = align_up((size_t)T * H * tw * 3);
+    return COGS_OK;
+}
+cogs_status cogs_preprocess_frames(cogs_stream stream, const uint8_t* frames, int T, int H, int W, int th, int tw,
+                                   int merge, const int32_t* bounds_x, const int32_t* coef_x, int ksx,
+                                   const int32_t* bounds_y, const int32_t* coef_y, int ksy, const float* value_table,
+                                   void* out, int out_dtype, void* ws, size_t ws_bytes) {
+    if (!frames || !out || !bounds_x || !coef_x || !bounds_y || !coef_y || !value_table) return COGS_E_INVALID;
+    if (!ws || ws_bytes < (size_t)T * H * tw * 3) return COGS_E_WORKSPACE;
+    return cogs_k_preprocess((hipStream_t)stream, frames, T, H, W, th, tw, merge, bounds_x, coef_x, ksx, bounds_y,
+                             coef_y, ksy, out, out_dtype, value_table, (uint8_t*)ws);
+}
+
 cogs_status cogs_argmax(cogs_stream stream, const float* logits, int n, int64_t* out, void* ws) {
     if (!ws) return COGS_E_WORKSPACE;
     return cogs_k_argmax((hipStream_t)stream, logits, n, out, (float*)ws);

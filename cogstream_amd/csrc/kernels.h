@@ -69,6 +69,11 @@ int cogs_k_vit_rope_table(hipStream_t st, float* cos_t, float* sin_t, int row0, 
 int cogs_k_llm_rope_table(hipStream_t st, float* cos_t, float* sin_t, const int* pos, int pos0, int rows,
                           const float* inv_freq, int n_freq);
 
+// GPU pre-processing: Pillow-exact bicubic resize + normalise + patchify (tmp: T*H*tw*3 bytes)
+int cogs_k_preprocess(hipStream_t st, const uint8_t* frames, int T, int H, int W, int th, int tw, int ms,
+                      const int* bx, const int* kx, int ksx, const int* by, const int* ky, int ksy, void* out,
+                      int out_dtype, const float* table, uint8_t* tmp);
+
 // token compression
 int cogs_k_pixdiff_mask(hipStream_t st, int dtype, const void* pix, int t, int tokens_per_frame, int row_elems,
                         float thr, int min_tokens, uint8_t* mask);

@@ -62,6 +62,90 @@ def _resize_bicubic(frame_hwc: np.ndarray, size: Tuple[int, int]) -> np.ndarray:
     return np.asarray(Image.fromarray(frame_hwc).resize((w, h), resample=Image.BICUBIC))
 
 
+# ---- Pillow's bicubic resample, restated exactly (third-party arithmetic the reference calls through
+# transformers.image_transforms.resize -> PIL.Image.resize(resample=BICUBIC); Pillow 10.4 src/libImaging/Resample.c:
+# precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc). Two passes
+# (horizontal first), double-precision coefficients normalised then fixed to 22 bits, uint8 rounding after EACH
+# pass. The GPU preprocessing kernels (csrc/preprocess.hip) consume the tables built here. ----
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x: float) -> float:
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def resample_coeffs(in_size: int, out_size: int):
+    """-> (bounds int32 [out,2] = (first input index, tap count), coeffs int32 [out, ksize], ksize)"""
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << _PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+def resize_bicubic_exact(frame_hwc: np.ndarray, size: Tuple[int, int]) -> np.ndarray:
+    """numpy restatement of PIL's RGB bicubic resize (bit-exact; tests pin it against PIL itself)"""
+    th, tw = size
+    h, w, c = frame_hwc.shape
+    img = frame_hwc.astype(np.int64)
+    half = 1 << (_PRECISION_BITS - 1)
+    if tw != w:
+        bx, kx, _ = resample_coeffs(w, tw)
+        out = np.empty((h, tw, c), dtype=np.int64)
+        for xx in range(tw):
+            x0, n = bx[xx]
+            out[:, xx, :] = half + (img[:, x0:x0 + n, :] * kx[xx, :n, None].astype(np.int64)).sum(axis=1)
+        img = np.clip(out >> _PRECISION_BITS, 0, 255)
+    if th != h:
+        by, ky, _ = resample_coeffs(h, th)
+        out = np.empty((th, img.shape[1], c), dtype=np.int64)
+        for yy in range(th):
+            y0, n = by[yy]
+            out[yy] = half + (img[y0:y0 + n] * ky[yy, :n, None, None].astype(np.int64)).sum(axis=0)
+        img = np.clip(out >> _PRECISION_BITS, 0, 255)
+    return img.astype(np.uint8)
+
+
+def pixel_value_table(rescale_factor: float = 0.00392156862745098, image_mean=(0.5, 0.5, 0.5),
+                      image_std=(0.5, 0.5, 0.5)) -> np.ndarray:
+    """fp32 [3,256]: what rescale + normalize make of each byte value per channel, in the reference's arithmetic
+    (transformers image_transforms.rescale: float64 product rounded to fp32; normalize: fp32 (x-mean)/std;
+    settings from model/preprocessor_config.json). Both the host path and the HIP kernel look values up here."""
+    u = np.arange(256, dtype=np.uint8)
+    x = (u.astype(np.float64) * rescale_factor).astype(np.float32)
+    mean = np.array(image_mean, dtype=np.float32)[:, None]
+    std = np.array(image_std, dtype=np.float32)[:, None]
+    return np.ascontiguousarray(((x[None, :] - mean) / std).astype(np.float32))
+
+
 def preprocess_videos(videos: Sequence[np.ndarray], merge_size: int = 2, min_tokens: int = 16,
                       max_tokens: int = 16384) -> Dict[str, np.ndarray]:
     """Videollama3ImageProcessor.preprocess (:349-473) for a list of clips, each uint8 [t, H, W, 3].
@@ -72,8 +156,7 @@ def preprocess_videos(videos: Sequence[np.ndarray], merge_size: int = 2, min_tok
     pix, grids = [], []
     for v, (th, tw) in zip(videos, targets):
         fr = np.stack([_resize_bicubic(f, (th, tw)) for f in v])                # [t, th, tw, 3] uint8
-        x = fr.astype(np.float32) * np.float32(0.00392156862745098)            # rescale_factor
-        x = (x - np.float32(0.5)) / np.float32(0.5)                              # image_mean/std = 0.5
+        x = pixel_value_table()[np.arange(3), fr]                               # [t, th, tw, 3] fp32
         x = x.transpose(0, 3, 1, 2)
         pix.append(patchify(x, merge_size))
         grids.append((v.shape[0], th // PATCH, tw // PATCH))
@@ -182,10 +265,15 @@ class CogStreamProcessor:
     """Videollama3Qwen2Processor.__call__ for in-memory clips (processing_cogreasoner.py:732-744,665):
     conversation items of type 'video' carry {'video': uint8 [t,H,W,3], 'timestamps': [...]}."""
 
-    def __init__(self, tokenizer, video_merge_size: int = 2, max_tokens: int = 16384, min_tokens: int = 16):
+    def __init__(self, tokenizer, video_merge_size: int = 2, max_tokens: int = 16384, min_tokens: int = 16,
+                 device=None, pixel_dtype=None):
+        """device=None: host PIL path (fp32 pixel_values on the CPU, as the reference returns them).
+        device='cuda:N': frames are uploaded as bytes and pre-processed by the HIP kernels (same values bit for
+        bit); pixel_values stay on the GPU in pixel_dtype (default bf16, the encoder's input dtype)."""
         self.tokenizer = tokenizer
         self.video_merge_size = video_merge_size
         self.max_tokens, self.min_tokens = max_tokens, min_tokens
+        self.device, self.pixel_dtype = device, pixel_dtype
 
     def __call__(self, conversation: List[Dict[str, Any]], add_system_prompt: bool = True,
                  add_generation_prompt: bool = True, return_tensors: str = "pt") -> Dict[str, Any]:
@@ -199,7 +287,7 @@ class CogStreamProcessor:
             items = []
             for c in msg["content"]:
                 if isinstance(c, dict) and c.get("type") == "video":
-                    v = np.asarray(c["video"])
+                    v = c["video"] if isinstance(c["video"], torch.Tensor) else np.asarray(c["video"])
                     ts = [float(t) for t in c.get("timestamps", range(len(v)))]
                     videos.append(v)
                     all_ts.extend(ts)
@@ -207,7 +295,17 @@ class CogStreamProcessor:
                 else:
                     items.append(c)
             conv.append({"role": msg["role"], "content": items})
-        feats = preprocess_videos(videos, self.video_merge_size, self.min_tokens, self.max_tokens) if videos else None
+        feats = None
+        if videos and self.device is not None:
+            from .preprocess_gpu import preprocess_videos_gpu
+            dev_videos = [(v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v)))
+                          .to(self.device, non_blocking=True).contiguous() for v in videos]
+            feats = preprocess_videos_gpu(dev_videos, self.video_merge_size, self.min_tokens, self.max_tokens,
+                                          out_dtype=self.pixel_dtype or torch.bfloat16)
+        elif videos:
+            host = preprocess_videos([v.cpu().numpy() if isinstance(v, torch.Tensor) else v for v in videos],
+                                     self.video_merge_size, self.min_tokens, self.max_tokens)
+            feats = {k: torch.from_numpy(a) for k, a in host.items()}
         text = render_conversation(conv, add_system_prompt, add_generation_prompt)
         per_image: List[int] = []
         if feats is not None:
@@ -223,9 +321,9 @@ class CogStreamProcessor:
             "all_timestamps": all_ts, "total_image_num": len(all_ts), "original_text": text,
         }
         if feats is not None:
-            out["pixel_values"] = torch.from_numpy(feats["pixel_values"])
-            out["grid_sizes"] = torch.from_numpy(feats["grid_sizes"])
-            out["merge_sizes"] = torch.from_numpy(feats["merge_sizes"])
+            out["pixel_values"] = feats["pixel_values"]
+            out["grid_sizes"] = feats["grid_sizes"]
+            out["merge_sizes"] = feats["merge_sizes"]
         return out
 
     def batch_decode(self, ids, **kw):

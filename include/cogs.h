@@ -164,6 +164,16 @@ cogs_status cogs_kmeans_update(cogs_stream stream, int dtype, const void* feats,
 cogs_status cogs_pack_rows(cogs_stream stream, int in_dtype, int out_dtype, const void* in, int64_t ld_in,
                            void* out, int64_t ld_out, int rows, int cols_in, int cols_out);
 
+/* GPU pre-processing (image_processing_videollama3.py:235-347): uint8 frames [T,H,W,3] -> Pillow-exact bicubic
+ * resize to (th,tw) -> value_table[c][byte] (fp32 [3,256], = rescale+normalize per byte) -> merge-window-major patch rows [T*(th/14)*(tw/14), 588] in out_dtype.
+ * bounds_* [out,2] / coef_* [out,ks*] are Pillow's per-output tap tables (device int32; built on the host,
+ * cogstream_amd.processing.resample_coeffs). ws >= T*H*tw*3 bytes. */
+cogs_status cogs_preprocess_workspace_bytes(int T, int H, int tw, size_t* bytes);
+cogs_status cogs_preprocess_frames(cogs_stream stream, const uint8_t* frames, int T, int H, int W, int th, int tw,
+                                   int merge, const int32_t* bounds_x, const int32_t* coef_x, int ksx,
+                                   const int32_t* bounds_y, const int32_t* coef_y, int ksy, const float* value_table,
+                                   void* out, int out_dtype, void* ws, size_t ws_bytes);
+
 /* logits post-processing (model/generation_config.json:2-12; qaselect_module_predict.py:86-103) */
 cogs_status cogs_argmax(cogs_stream stream, const float* logits, int n, int64_t* out, void* ws /* >= 512 B */);
 cogs_status cogs_logits_process(cogs_stream stream, float* logits, int n, const int64_t* prev, int n_prev,

@@ -94,6 +94,33 @@ def golden_vit():
          proj_checksum=np.float64(checksum(pst)))
 
 
+def golden_preprocess():
+    """Videollama3ImageProcessor.preprocess (the reference's own class) on two small seeded clips of different
+    sizes; stores the reference's pixel_values / grid_sizes, plus the per-byte value table it implies."""
+    # transformers 5.x (this image) moved the `VideoInput` type alias from image_utils to video_utils; the
+    # reference (pinned to 4.46.3) imports it from the old place and uses it in annotations only.
+    import transformers.image_utils as _iu
+    import transformers.video_utils as _vu
+    if not hasattr(_iu, "VideoInput"):
+        _iu.VideoInput = _vu.VideoInput
+    from model.image_processing_videollama3 import Videollama3ImageProcessor
+    from cogstream_amd.processing import synthetic_clip
+    with open("/root/reference/model/preprocessor_config.json") as f:       # the shipped processor settings
+        pc = json.load(f)
+    proc = Videollama3ImageProcessor(**{k: pc[k] for k in ("do_resize", "resample", "do_rescale", "rescale_factor",
+                                                           "do_normalize", "image_mean", "image_std", "do_convert_rgb",
+                                                           "min_tokens", "max_tokens", "patch_size")})
+    clips = [synthetic_clip(2, 60, 100, kind="drift", clip_idx=5)[0], synthetic_clip(1, 90, 70, kind="noise", clip_idx=6)[0]]
+    out = proc.preprocess(images=[[f for f in c] for c in clips], merge_size=2, return_tensors="np")
+    ramp = np.arange(256, dtype=np.uint8).reshape(1, 16, 16, 1).repeat(3, axis=3)
+    ramp = np.tile(ramp, (1, 2, 2, 1))[:, :28, :28]                 # one 28x28 frame, no resize needed
+    lut_out = proc.preprocess(images=[[ramp[0]]], merge_size=2, return_tensors="np")
+    save("preprocess.npz", clip_args=np.array([[2, 60, 100, 5], [1, 90, 70, 6]]),
+         pixel_values=out["pixel_values"].astype(np.float32), grid_sizes=out["grid_sizes"],
+         merge_sizes=out["merge_sizes"], ramp=ramp, ramp_pixel_values=lut_out["pixel_values"].astype(np.float32),
+         ramp_grid=lut_out["grid_sizes"])
+
+
 def golden_kmeans():
     cases = {}
     for ci, (T, P, D, K, seed) in enumerate([(150, 3, 16, 10, 0), (64, 2, 8, 5, 1), (40, 1, 32, 6, 2), (6, 2, 4, 8, 3)]):
@@ -280,6 +307,9 @@ def golden_e2e():
 
 
 if __name__ == "__main__":
+    golden_preprocess()
+    if "--only-preprocess" in sys.argv:
+        sys.exit(0)
     which = sys.argv[1:] or ["vit", "kmeans", "compress", "text", "e2e"]
     with torch.no_grad():
         for w in which:

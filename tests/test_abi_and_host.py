@@ -110,3 +110,14 @@ def test_frame_shards():
     from cogstream_amd.parallel import frame_shards
     assert frame_shards(64, 8) == [(8 * i, 8 * i + 8) for i in range(8)]
     assert frame_shards(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_pillow_resample_restatement_is_bit_exact():
+    """cogstream_amd.processing.resize_bicubic_exact (the algorithm the GPU kernels implement) against PIL itself"""
+    from PIL import Image
+    from cogstream_amd import processing as pr
+    rng = np.random.default_rng(1)
+    for (h, w, th, tw) in [(120, 214, 84, 140), (60, 60, 60, 60), (33, 47, 56, 84), (96, 50, 28, 28)]:
+        f = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(f).resize((tw, th), resample=Image.BICUBIC))
+        assert np.array_equal(pr.resize_bicubic_exact(f, (th, tw)), ref), (h, w, th, tw)

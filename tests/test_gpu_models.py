@@ -122,3 +122,18 @@ def test_llm_sampling_runs_and_respects_topk(dev):
     toks = eng.generate(emb, max_new_tokens=8, do_sample=True, temperature=0.7, top_k=20, top_p=0.8,
                         repetition_penalty=1.05, generator=g, ignore_eos=True)
     assert len(toks) == 8 and all(0 <= t < cfg.vocab_size for t in toks)
+
+
+def test_processor_gpu_path_equals_host_path(dev):
+    """CogStreamProcessor(device=...) returns the same pixel_values (bf16 of the host fp32) and the same text side"""
+    from cogstream_amd import processing as pr
+    from toy_tokenizer import ToyTokenizer
+    tok = ToyTokenizer()
+    frames, ts = pr.synthetic_clip(3, 120, 214, kind="drift", clip_idx=2)
+    conv = [{"role": "user", "content": [{"type": "video", "video": frames, "timestamps": ts},
+                                         {"type": "text", "text": "what moves?"}]}]
+    host = pr.CogStreamProcessor(tok)(conv)
+    gpu = pr.CogStreamProcessor(tok, device=dev)(conv)
+    assert gpu["pixel_values"].is_cuda and gpu["pixel_values"].dtype == torch.bfloat16
+    assert torch.equal(gpu["pixel_values"].cpu(), host["pixel_values"].bfloat16())
+    assert torch.equal(gpu["grid_sizes"], host["grid_sizes"]) and torch.equal(gpu["input_ids"], host["input_ids"])

@@ -338,3 +338,18 @@ def test_kmeans_steps(dev, dtype):
     rs = torch.norm(ncf - cf, dim=1).sum() + torch.norm(nct - ct)
     assert rel_err(cg, ncf) < 1e-5 and rel_err(ctg, nct) < 1e-6
     assert abs(float(shift) - float(rs)) / float(rs) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(3, 120, 214), (2, 56, 84), (4, 480, 854)])
+def test_gpu_preprocessing_bit_exact_vs_pil_path(dev, shape):
+    """uint8 frames -> pixel_values on the GPU == the PIL host path (fp32 bit-identical, bf16 = one rounding)"""
+    from cogstream_amd import processing as pr
+    from cogstream_amd.preprocess_gpu import preprocess_videos_gpu
+    t, h, w = shape
+    frames, _ = pr.synthetic_clip(t, h, w, kind="drift", clip_idx=3)
+    ref = pr.preprocess_videos([frames])
+    got = preprocess_videos_gpu([torch.from_numpy(frames).to(dev)], out_dtype=torch.float32)
+    assert got["grid_sizes"].tolist() == ref["grid_sizes"].tolist()
+    assert torch.equal(got["pixel_values"].cpu(), torch.from_numpy(ref["pixel_values"]))
+    got16 = preprocess_videos_gpu([torch.from_numpy(frames).to(dev)], out_dtype=torch.bfloat16)
+    assert torch.equal(got16["pixel_values"].cpu(), torch.from_numpy(ref["pixel_values"]).bfloat16())

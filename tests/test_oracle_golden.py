@@ -112,3 +112,22 @@ def test_host_text_logic_matches_reference():
     ex = {"current_Q": t["current_question"], "hist_Qs": t["hist_qs"], "hist_As": t["hist_as"]}
     assert format_example(ex) == t["qa_prompt"]
     assert format_example(ex, include_demo=False) == t["qa_prompt_nodemo"]
+
+
+def test_preprocessing_matches_reference_processor_bit_exact():
+    """host pre-processing against the reference's Videollama3ImageProcessor output (tests/golden/make_golden.py)"""
+    from cogstream_amd import processing as pr
+    g = np.load(os.path.join(G, "preprocess.npz"))
+    clips = [pr.synthetic_clip(int(a[0]), int(a[1]), int(a[2]), kind=k, clip_idx=int(a[3]))[0]
+             for a, k in zip(g["clip_args"], ["drift", "noise"])]
+    out = pr.preprocess_videos(clips)
+    assert out["grid_sizes"].tolist() == g["grid_sizes"].tolist()
+    assert out["merge_sizes"].tolist() == g["merge_sizes"].tolist()
+    assert np.array_equal(out["pixel_values"], g["pixel_values"])
+    ramp = pr.preprocess_videos([g["ramp"]])
+    assert ramp["grid_sizes"].tolist() == g["ramp_grid"].tolist()
+    assert np.array_equal(ramp["pixel_values"], g["ramp_pixel_values"])
+    # the pure-numpy resample restatement (what the HIP kernels implement) gives the same image as PIL
+    fr = clips[0][0]
+    th, tw = int(g["grid_sizes"][0][1]) * 14, int(g["grid_sizes"][0][2]) * 14
+    assert np.array_equal(pr.resize_bicubic_exact(fr, (th, tw)), pr._resize_bicubic(fr, (th, tw)))
