@@ -293,8 +293,8 @@ static size_t vit_carve(const cogs_vit_weights& w, int64_t N, int nframes, Carve
     *ln = c.take((size_t)N * w.hidden * es);
     const size_t bigcols = (size_t)(4 * w.hidden > w.inter_pad ? 4 * w.hidden : w.inter_pad);
     *big = c.take((size_t)N * bigcols * es);  // [qkv | attn_out] then reused as the MLP hidden
-    *rc = (float*)c.take((size_t)N * (hd / 2) * sizeof(float));
-    *rs = (float*)c.take((size_t)N * (hd / 2) * sizeof(float));
+    *rc = (float*)c.take((size_t)N * (hd / 2) * 2 * sizeof(float));   // interleaved (cos, sin) table
+    *rs = nullptr;
     *cu = (int32_t*)c.take((size_t)(nframes + 1) * sizeof(int32_t));
     *lo = (int32_t*)c.take((size_t)N * sizeof(int32_t));
     *hi = (int32_t*)c.take((size_t)N * sizeof(int32_t));
@@ -488,8 +488,8 @@ static size_t llm_carve(const cogs_llm_weights& w, int S, int max_ctx, Carver& c
     *qkv = c.take((size_t)S * qd * es);
     *att = c.take((size_t)S * w.heads * w.head_dim * es);
     *act = c.take((size_t)S * w.inter * es);
-    *rc = (float*)c.take((size_t)S * (w.head_dim / 2) * sizeof(float));
-    *rs = (float*)c.take((size_t)S * (w.head_dim / 2) * sizeof(float));
+    *rc = (float*)c.take((size_t)S * (w.head_dim / 2) * 2 * sizeof(float));   // interleaved (cos, sin) table
+    *rs = nullptr;
     *split_bytes = (size_t)llm_nsplit(max_ctx) * w.heads * (w.head_dim + 2) * sizeof(float);
     *split = c.take(*split_bytes);
     return c.off;

@@ -44,6 +44,7 @@ struct GemmArgs {
     const char* W; long ldw;   // bytes per row
     int M, N, K;
     int nbm, nbn;
+    unsigned long long* trace;   // diagnostics (COGS_GEMM_TRACE): per-tile s_memtime stamps of WG 0, waves 0 and 4
     EpiArgs epi;
 };
 
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs p) {
     constexpr int BK = ElemCfg<T>::BK;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
 
     // ---- block -> tile (XCD-aware, bijective; then grouped walk) ----
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs p) {
 #undef COGS_TOUCH1
 
     // ---- epilogue: lane holds C[m][n..n+3], m = ..+(lane&15), n = ..+4*(lane>>4) ----
-    epilogue_tile<T, EPI>(p.epi, m0 + wm * 64, n0 + wn * 64, p.M, p.N, lane, acc);
+    epilogue_wave<T, EPI>(p.epi, m0 + wm * 64, n0 + wn * 64, p.M, p.N, lane, acc);
 }
 
 
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x128_kernel(GemmArgs p) {
     constexpr int BK = ElemCfg<T>::BK;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int nb = p.nbm * p.nbn;
     const int KT = p.K / BK;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x128_kernel(GemmArgs p) {
             __builtin_amdgcn_s_setprio(0);
             buf = nbuf;
         }
-        epilogue_tile<T, EPI>(p.epi, m0 + wm * 64, n0 + wn * 64, p.M, p.N, lane, acc);
+        epilogue_wave<T, EPI>(p.epi, m0 + wm * 64, n0 + wn * 64, p.M, p.N, lane, acc);
         epi_stores = (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0 &&
                       (p.N & 31) == 0 && m0 + BM2 <= p.M && n0 + BN <= p.N) ? 8 : 0;
     }
@@ -365,6 +366,9 @@ constexpr int BM3 = 256, BN3 = 256;
 constexpr int ROW3 = 64;                          // bytes per LDS row = 32 bf16
 constexpr int SLOT3 = (BM3 + BN3) * ROW3;         // 32 KiB per K-tile
 constexpr int RING3 = 4;
+#ifndef PP_TAIL
+#define PP_TAIL 0   // MFMA rows (x4 MFMAs) of a C segment issued after its closing barrier (1: measured 10 % slower -- the L segment, not the barrier round trip, is what an interval waits for)
+#endif
 
 __device__ __forceinline__ int swz3(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }   // [0,2,3,1]
 
@@ -467,6 +471,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
 
     int slot = 0;
     int g = 0;   // index of the K-tile being consumed (0..total-1)
+    const bool tracing = p.trace && blockIdx.x == 0 && wc == 0;
+    int trace_i = 0;
+    auto stamp = [&]() {
+        if (tracing && trace_i < 96) {
+            const unsigned long long tm = __builtin_amdgcn_s_memtime();
+            if (lane == 0) p.trace[grp * 96 + trace_i] = tm;
+            ++trace_i;
+        }
+    };
     for (int t = blockIdx.x; t < nb; t += gridDim.x) {
         int m0, n0;
         tile_origin(t, m0, n0);
@@ -476,6 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stamp();
         for (int kt = 0; kt < KT; ++kt, ++g) {
             const char* base = smem + slot * SLOT3;
             // ---- phase 0: L segment ----
@@ -495,14 +509,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
             // ---- phase 0: C segment ----
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4 - PP_TAIL; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[0][mi][ni], 0, 0, 0);
+            // hand the matrix pipe over EARLY: the other group is released while this wave's last PP_TAIL*4 MFMAs are
+            // still queued, so the pipe does not drain for a barrier round trip every interval
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 4 - PP_TAIL; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[0][mi][ni], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
             // ---- phase 1: L segment ----
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -519,20 +543,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
             // ---- phase 1: C segment ----
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4 - PP_TAIL; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[1][mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 0) wait_next_ktile(ahead, kt);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 4 - PP_TAIL; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[1][mi][ni], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             asm volatile("" ::: "memory");
-            if (grp == 0) wait_next_ktile(ahead, kt);
-            __builtin_amdgcn_s_barrier();
             slot = (slot + 1) & 3;
         }
         // epilogue of this tile; it runs inside this group's next L interval, i.e. beside the other group's C
-        epilogue_tile<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0]);
-        epilogue_tile<T, EPI>(p.epi, m0 + grp * 128 + 64, n0 + wc * 64, p.M, p.N, lane, acc[1]);
+        stamp();
+        epilogue_wave<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0]);
+        epilogue_wave<T, EPI>(p.epi, m0 + grp * 128 + 64, n0 + wc * 64, p.M, p.N, lane, acc[1]);
+        stamp();
         epi_stores = (WIDE_EPI && (p.N & 31) == 0 && m0 + BM3 <= p.M && n0 + BN3 <= p.N) ? 16 : 0;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
@@ -573,6 +607,25 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
+    }
+    static const bool env_trace = getenv("COGS_GEMM_TRACE") != nullptr;
+    if (env_trace) {
+        static unsigned long long* dbuf = nullptr;
+        if (!dbuf) (void)hipMalloc(&dbuf, 192 * 8);
+        (void)hipMemsetAsync(dbuf, 0, 192 * 8, st);
+        GemmArgs q = p;
+        q.trace = dbuf;
+        hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, q);
+        unsigned long long h[192];
+        (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        for (int g = 0; g < 2; ++g) {
+            fprintf(stderr, "[gemm trace] EPI=%d M=%d N=%d K=%d group %d:", EPI, p.M, p.N, p.K, g);
+            for (int i = 0; i + 2 < 96 && h[g * 96 + i + 2]; i += 3)
+                fprintf(stderr, " k%llu/e%llu", h[g * 96 + i + 1] - h[g * 96 + i], h[g * 96 + i + 2] - h[g * 96 + i + 1]);
+            fprintf(stderr, "\n");
+        }
+        return;
     }
     hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, p);
 }
@@ -624,6 +677,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     if (g.M == 1) return cogs_k_gemv(st, g);
     if (g.rms_gamma) return COGS_E_UNSUPPORTED;   // fused RMSNorm exists for the single-token GEMV only
     GemmArgs p;
+    p.trace = nullptr;
     const int rc = cogs_fill_epi(g, &p.epi);
     if (rc != COGS_OK) return rc;
     p.A = (const char*)g.A; p.lda = g.lda * es;

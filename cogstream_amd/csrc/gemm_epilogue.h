@@ -4,7 +4,8 @@
 //   bias      + b[n..n+3]
 //   rope      columns < rope_cols: weight rows were packed so that (n, n+1) is the rotary pair
 //             (d, d+hd/2) of rotate_half (model/modeling_videollama3_encoder.py:154-170; Qwen2
-//             apply_rotary_pos_emb); cos/sin tables are [M, hd/2] fp32
+//             apply_rotary_pos_emb); cos/sin tables are [M, hd/2] fp32, or -- rope_sin == NULL -- ONE
+//             interleaved table [M, hd/2, 2] = (cos, sin) in rope_cos (a lane's two pairs = one 16-byte load)
 //   act       gelu_pytorch_tanh (ViT fc1), erf GELU (projector), SwiGLU on (gate_i, up_i)-interleaved
 //             rows (Qwen2 MLP) -> two outputs at column n/2
 //   residual  + R[m][n..n+3]
@@ -41,13 +42,24 @@ struct EpiArgs {
     int head_dim;
 };
 
+// (cos, sin) of the two rotary pairs pi, pi+1 of row m, from either table format
+__device__ __forceinline__ void rope_load(const EpiArgs& p, long m, int pi, f32x2& c, f32x2& s) {
+    if (p.rope_sin) {
+        c = *reinterpret_cast<const f32x2*>(p.rope_cos + m * p.rope_pairs + pi);
+        s = *reinterpret_cast<const f32x2*>(p.rope_sin + m * p.rope_pairs + pi);
+    } else {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.rope_cos + (m * p.rope_pairs + pi) * 2);
+        c = f32x2{t[0], t[2]};
+        s = f32x2{t[1], t[3]};
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void epilogue4(const EpiArgs& p, int m, int n, f32x4 v) {
     if (p.bias) v += ld4_f<T>(reinterpret_cast<const T*>(p.bias) + n);
     if (p.rope_cos && n < p.rope_cols) {
-        const int pi = (n % p.head_dim) >> 1;
-        const f32x2 c = *reinterpret_cast<const f32x2*>(p.rope_cos + (long)m * p.rope_pairs + pi);
-        const f32x2 s = *reinterpret_cast<const f32x2*>(p.rope_sin + (long)m * p.rope_pairs + pi);
+        f32x2 c, s;
+        rope_load(p, m, (n % p.head_dim) >> 1, c, s);
         f32x4 r;
         r[0] = v[0] * c[0] - v[1] * s[0];
         r[1] = v[1] * c[0] + v[0] * s[0];
@@ -167,9 +179,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) {
-                        const int pi = (nn[ni] % p.head_dim) >> 1;
-                        cs[i][ni] = *reinterpret_cast<const f32x2*>(p.rope_cos + (long)mm[i] * p.rope_pairs + pi);
-                        sn[i][ni] = *reinterpret_cast<const f32x2*>(p.rope_sin + (long)mm[i] * p.rope_pairs + pi);
+                        rope_load(p, mm[i], (nn[ni] % p.head_dim) >> 1, cs[i][ni], sn[i][ni]);
                     }
             }
 #pragma unroll
@@ -245,6 +255,134 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
             }
         }
     }
+}
+
+// Interior wave tile on the wide path (bf16 output, whole 64x64 tile inside the matrix, 16-byte aligned rows,
+// rotary either on or off for the whole tile): the same arithmetic as epilogue_tile() with lean addressing.
+// The general path spends ~5000 VALU cycles per wave and tile on 64-bit `row * ld` products (quarter-rate
+// v_mul_lo_u32 / v_mad_u64_u32) and per-store exec masking -- measured 8-10 % of a K = 1152 GEMM. Here the
+// tile base is wave-uniform (SGPRs), a lane adds ONE 32-bit byte offset, rows advance by a uniform stride,
+// nothing is predicated, and the rotary (cos, sin) pairs come from the interleaved table with one 16-byte load.
+template <int EPI>
+__device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int nb, int lane, f32x4 (&acc)[4][4]) {
+    typedef bf16_t T;
+    const int r = lane & 15, g4 = lane >> 4;
+    const int wcol = 16 * (g4 & 1) + 8 * (g4 >> 1);
+    char* const cbase = p.C + ((long)mb * p.ldc + nb) * 2;
+    const unsigned c_lane = ((unsigned)r * (unsigned)p.ldc + (unsigned)wcol) * 2u;
+    const long c_row16 = p.ldc * 32;
+    const char* rbase = nullptr;
+    unsigned r_lane = 0;
+    long r_row16 = 0;
+    if constexpr ((EPI & EPI_RES) != 0) {
+        rbase = p.R + ((long)mb * p.ldr + nb) * 2;
+        r_lane = ((unsigned)r * (unsigned)p.ldr + (unsigned)wcol) * 2u;
+        r_row16 = p.ldr * 32;
+    }
+    f32x4 bias_v[4];
+    if constexpr ((EPI & EPI_BIAS) != 0) {
+        const char* bbase = reinterpret_cast<const char*>(p.bias) + (long)nb * 2;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bias_v[ni] = ld4_f<T>(reinterpret_cast<const T*>(bbase + (unsigned)(g4 * 8 + ni * 32)));
+    }
+    const char* csbase = nullptr;
+    unsigned cs_lane[4] = {0, 0, 0, 0};
+    long cs_row16 = 0;
+    if constexpr ((EPI & EPI_ROPE) != 0) {
+        csbase = reinterpret_cast<const char*>(p.rope_cos) + (long)mb * p.rope_pairs * 8;
+        cs_row16 = (long)p.rope_pairs * 128;
+        const int nbmod = nb % p.head_dim;     // wave-uniform
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            int c = nbmod + 16 * ni + 4 * g4;  // < 2 * head_dim (head_dim >= 64)
+            c -= c >= p.head_dim ? p.head_dim : 0;
+            cs_lane[ni] = (unsigned)(r * p.rope_pairs * 8 + c * 4);
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        u32x4 res_wide[2][2];
+        f32x4 cs4[2][4];
+        if constexpr ((EPI & EPI_RES) != 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+                    res_wide[i][pr] = *reinterpret_cast<const u32x4*>(rbase + (2 * half + i) * r_row16 + r_lane + 64 * pr);
+        }
+        if constexpr ((EPI & EPI_ROPE) != 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    cs4[i][ni] = *reinterpret_cast<const f32x4*>(csbase + (2 * half + i) * cs_row16 + cs_lane[ni]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mi = 2 * half + i;
+            f32x4 v[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                v[ni] = acc[mi][ni];
+                if constexpr ((EPI & EPI_BIAS) != 0) v[ni] += bias_v[ni];
+                if constexpr ((EPI & EPI_ROPE) != 0) {
+                    const f32x4 t = cs4[i][ni];   // c0 s0 c1 s1
+                    f32x4 q;
+                    q[0] = v[ni][0] * t[0] - v[ni][1] * t[1];
+                    q[1] = v[ni][1] * t[0] + v[ni][0] * t[1];
+                    q[2] = v[ni][2] * t[2] - v[ni][3] * t[3];
+                    q[3] = v[ni][3] * t[2] + v[ni][2] * t[3];
+                    v[ni] = q;
+                }
+                if constexpr ((EPI & EPI_GELU_TANH) != 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[ni][e] = gelu_tanh_f(v[ni][e]);
+                }
+                if constexpr ((EPI & EPI_GELU_ERF) != 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[ni][e] = gelu_erf_f(v[ni][e]);
+                }
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x4 va = v[2 * pr], vb = v[2 * pr + 1];
+                if constexpr ((EPI & EPI_RES) != 0) {
+                    const u32x4 rw = res_wide[i][pr];
+                    const auto x0 = __builtin_amdgcn_permlane16_swap(rw[0], rw[2], false, false);
+                    const auto x1 = __builtin_amdgcn_permlane16_swap(rw[1], rw[3], false, false);
+                    va += f32x4{bf_lo(x0[0]), bf_hi(x0[0]), bf_lo(x1[0]), bf_hi(x1[0])};
+                    vb += f32x4{bf_lo(x0[1]), bf_hi(x0[1]), bf_lo(x1[1]), bf_hi(x1[1])};
+                }
+                const unsigned a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]);
+                const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                *reinterpret_cast<u32x4*>(cbase + mi * c_row16 + c_lane + 64 * pr) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+        }
+    }
+}
+
+// Epilogue of one wave's 64x64 tile: the lean path when the (wave-uniform) conditions hold, else the general one.
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_wave(const EpiArgs& p, int mb, int nb, int M, int N, int lane,
+                                              f32x4 (&acc)[4][4]) {
+    if constexpr (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0) {
+        bool fast = mb + 64 <= M && nb + 64 <= N && (N & 31) == 0 && (p.ldc & 7) == 0 &&
+                    (reinterpret_cast<unsigned long>(p.C) & 15) == 0;
+        if constexpr ((EPI & EPI_RES) != 0) fast = fast && (p.ldr & 7) == 0 && (reinterpret_cast<unsigned long>(p.R) & 15) == 0;
+        if constexpr ((EPI & EPI_ROPE) != 0) {
+            fast = fast && p.rope_sin == nullptr && p.head_dim >= 64 && (nb + 64 <= p.rope_cols || nb >= p.rope_cols);
+            if (fast) {
+                if (nb < p.rope_cols) epilogue_tile_fast<EPI>(p, mb, nb, lane, acc);
+                else epilogue_tile_fast<(EPI & ~EPI_ROPE)>(p, mb, nb, lane, acc);
+                return;
+            }
+        } else {
+            if (fast) { epilogue_tile_fast<EPI>(p, mb, nb, lane, acc); return; }
+        }
+    }
+    epilogue_tile<T, EPI>(p, mb, nb, M, N, lane, acc);
 }
 
 inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {

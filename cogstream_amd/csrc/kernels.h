@@ -20,7 +20,7 @@ struct CogsGemm {
     int M = 0, N = 0, K = 0;
     int act = 0;
     int out_f32 = 0;
-    const float* rope_cos = nullptr;         // [M, head_dim/2]
+    const float* rope_cos = nullptr;         // [M, head_dim/2], or interleaved [M, head_dim/2, 2] when rope_sin == nullptr
     const float* rope_sin = nullptr;
     int rope_cols = 0;
     int head_dim = 0;

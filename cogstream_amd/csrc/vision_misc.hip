@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void vit_rope_kernel(float* cos_t, float* sin_
         const int wpos = (win % wpr) * ms + in % ms;
         const float ang = (f < nf) ? (float)hpos * inv_freq[f] : (float)wpos * inv_freq[f - nf];
         const long o = ((long)row0 + row) * (2 * nf) + f;
-        cos_t[o] = cosf(ang);
-        sin_t[o] = sinf(ang);
+        if (sin_t) { cos_t[o] = cosf(ang); sin_t[o] = sinf(ang); }
+        else { cos_t[2 * o] = cosf(ang); cos_t[2 * o + 1] = sinf(ang); }   // interleaved (cos, sin)
     }
 }
 
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void llm_rope_kernel(float* cos_t, float* sin_
         const int r = (int)(i / nf);
         const int pp = pos ? pos[r] : pos0 + r;
         const float ang = (float)pp * inv_freq[f];
-        cos_t[i] = cosf(ang);
-        sin_t[i] = sinf(ang);
+        if (sin_t) { cos_t[i] = cosf(ang); sin_t[i] = sinf(ang); }
+        else { cos_t[2 * i] = cosf(ang); cos_t[2 * i + 1] = sinf(ang); }   // interleaved (cos, sin)
     }
 }
 

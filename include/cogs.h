@@ -77,7 +77,8 @@ cogs_status cogs_profile_end(cogs_handle h, cogs_stream stream, float* ms_per_cl
  * (model/modeling_videollama3_encoder.py:194-210,246-248,275,369-373; cogreasoner_chat.py:179-211).
  * K must be a multiple of 64 (bf16) / 32 (f32) -- pad with zeros; N a multiple of 4;
  * lda/ldw/ldc/ldr in elements, rows 16-byte aligned. bias [N] and residual [M,N] nullable.
- * rope: if rope_cos != NULL, columns [0, rope_cols) are rotated with tables [M, head_dim/2] (fp32);
+ * rope: if rope_cos != NULL, columns [0, rope_cols) are rotated with tables [M, head_dim/2] (fp32), or --
+ * rope_sin == NULL -- with ONE interleaved table [M, head_dim/2, 2] = (cos, sin) in rope_cos (faster);
  * weight rows must be packed so that columns (2i, 2i+1) of a head are the rotate_half pair
  * (i, i + head_dim/2). act = COGS_ACT_*; SWIGLU writes [M, N/2]. out_f32: store fp32. */
 typedef struct {

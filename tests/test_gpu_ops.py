@@ -83,12 +83,15 @@ def test_gemm_swiglu(dev, M):
     assert rel_err(out.float(), ref) < 1.2e-2
 
 
-@pytest.mark.parametrize("M", [1, 96])
-def test_gemm_rope_epilogue(dev, M):
-    """columns [0, rope_cols) rotated as rotate_half pairs after the (d, d+hd/2) row interleave"""
+@pytest.mark.parametrize("M,heads,interleaved", [(1, 2, False), (96, 2, False), (96, 2, True), (1300, 2, True),
+                                                 (1300, 7, True), (1300, 7, False)])
+def test_gemm_rope_epilogue(dev, M, heads, interleaved):
+    """columns [0, rope_cols) rotated as rotate_half pairs after the (d, d+hd/2) row interleave; both table
+    formats; M = 1300 reaches the 256x128 (heads 2) and ping-pong (heads 7) kernels, whose interior wave tiles
+    take the lean epilogue while the tile straddling rope_cols and the ragged last row block take the general one"""
     ops = _ops()
     torch.manual_seed(3)
-    hd, heads, K = 72, 2, 128
+    hd, K = 72, 128
     N = 3 * heads * hd  # q | k | v, v not rotated
     x = torch.randn(M, K).bfloat16()
     w = (torch.randn(N, K) / 11).bfloat16()
@@ -107,7 +110,8 @@ def test_gemm_rope_epilogue(dev, M):
     wp[:2 * heads] = wp[:2 * heads][:, perm]
     bp[:2 * heads] = bp[:2 * heads][:, perm]
     out = ops.gemm(x.to(dev), wp.reshape(N, K).contiguous().to(dev), bp.reshape(N).contiguous().to(dev),
-                   rope_cos=ang.cos().contiguous().to(dev), rope_sin=ang.sin().contiguous().to(dev),
+                   rope_cos=(torch.stack([ang.cos(), ang.sin()], -1) if interleaved else ang.cos()).contiguous().to(dev),
+                   rope_sin=None if interleaved else ang.sin().contiguous().to(dev),
                    rope_cols=2 * heads * hd, head_dim=hd)
     refp = ref.clone()
     refp[:, :2 * heads] = ref[:, :2 * heads][:, :, perm]

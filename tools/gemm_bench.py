@@ -23,7 +23,7 @@ def rnd(*s):
 cases = []
 if which == "vit":
     H, I = 1152, 4352
-    cos = torch.rand(M, 36, device=dev)
+    cos = torch.rand(M, 36, 2, device=dev)   # interleaved (cos, sin)
     cases = [
         ("qkv  N3456 K1152 plain", dict(N=3456, K=H)),
         ("qkv  +bias+rope", dict(N=3456, K=H, bias=True, rope=(cos, 2304, 72))),
@@ -56,7 +56,7 @@ for name, c in cases:
         kw["act"] = c["act"]
     if c.get("rope"):
         t, cols, hd = c["rope"]
-        kw.update(rope_cos=t, rope_sin=t, rope_cols=cols, head_dim=hd)
+        kw.update(rope_cos=t, rope_sin=None, rope_cols=cols, head_dim=hd)
     out = torch.empty(M, c["N"] // 2 if c.get("act") == L.ACT_SWIGLU else c["N"], device=dev, dtype=bf)
     prepared.append((name, a, w, kw, out, 2.0 * M * c["N"] * c["K"]))
 

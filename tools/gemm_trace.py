@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-tile cycle stamps of the ping-pong GEMM (COGS_GEMM_TRACE=1): K-loop / epilogue cycles of workgroup 0."""
+import os
+import sys
+
+os.environ["COGS_GEMM_TRACE"] = "1"
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cogstream_amd import _lib as L  # noqa: E402
+from cogstream_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+M = 59136
+bf = torch.bfloat16
+for name, N, K, kw in [("qkv plain", 3456, 1152, {}), ("fc1 plain", 4352, 1152, {}),
+                       ("fc1 gelu", 4352, 1152, dict(bias=True, act=L.ACT_GELU_TANH)), ("fc2 res", 1152, 4352, dict(res=True))]:
+    a = (torch.rand(M, K, device=dev) - 0.5).to(bf)
+    w = ((torch.rand(N, K, device=dev) - 0.5) * 0.05).to(bf)
+    args = {}
+    if kw.get("bias"):
+        args["bias"] = torch.zeros(N, device=dev, dtype=bf)
+    if kw.get("res"):
+        args["residual"] = torch.zeros(M, N, device=dev, dtype=bf)
+    if kw.get("act"):
+        args["act"] = kw["act"]
+    print("==", name, file=sys.stderr)
+    for _ in range(2):
+        ops.gemm(a, w, **args)
+    torch.cuda.synchronize()
