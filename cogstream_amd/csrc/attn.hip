@@ -43,6 +43,19 @@ struct AttnArgs {
     float* part_ml;                 // [nsplit][q_len][hq][2]  (running max (log2 domain), sum)
 };
 
+// max over the four lanes {li, li+16, li+32, li+48} (one query column), result in all four, without an LDS round
+// trip: v_permlane16_swap(x, x) leaves [r0 r0 r2 r2] / [r1 r1 r3 r3] (odd rows of the first <-> even rows of the
+// second operand), v_permlane32_swap(y, y) leaves [lo lo] / [hi hi]. ds_bpermute (what __shfl_xor compiles to) put
+// two dependent ~100-cycle LDS latencies into every tile's softmax.
+__device__ __forceinline__ float colgroup_max(float x) {
+    const unsigned xb = __builtin_bit_cast(unsigned, x);
+    const auto a = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
+    const float y = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    const unsigned yb = __builtin_bit_cast(unsigned, y);
+    const auto b = __builtin_amdgcn_permlane32_swap(yb, yb, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+
 __device__ __forceinline__ int k_swz(int row) { return (row & 3) | (((row >> 3) & 3) << 2); }
 
 template <int HD>
@@ -191,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
     // V transposed read: lane i of a 16-lane group supplies row k0 + (i>>2), cols d0 + 4(i&3)
     const int vrow_off = g * VG + (li >> 2) * VS + (li & 3) * 8;
 
+    const bool wave_active = p.gqa_pack ? (wid == 0) : (q0 + wid * 32 < qe);   // wave-uniform
     if (t_begin < nt) load_tile(t_begin);
     // one K/V tile; MASKED is a compile-time tag: interior tiles run a compare-free softmax body, only the
     // tiles that touch the key-range end, the causal diagonal or the bias mode evaluate masks. (A run-time
@@ -201,11 +215,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
         write_tile();
         __syncthreads();
         if (kt + 1 < nt) load_tile(kt + 1);
+        // a wave whose 32 query rows all lie past the segment end (the ragged last q-block: 924 = 7*128 + 28)
+        // only stages and synchronises; its SIMD time goes to the co-resident workgroup
+        if (!wave_active) return;
 
         const int kbase = ks + kt * 64;
+        // ragged last key tile: when the second 32-key half is entirely past the range its MFMAs are skipped
+        // (wave-uniform; P of that half would be exactly zero)
+        const bool second_half = !MASKED || kbase + 32 < kend;
         f32x4 sacc[4][2];
 #pragma unroll
         for (int ut = 0; ut < 4; ++ut) {
+            if (MASKED && ut >= 2 && !second_half) {
+                sacc[ut][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sacc[ut][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             const int krow = 32 * (ut >> 1) + 4 * (ut & 1) + krow0;
             const int ksw = k_swz(krow);
 #pragma unroll
@@ -249,8 +274,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
                     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[ut][qi][r]);
                 mx *= p.scale_log2;   // scale > 0
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = colgroup_max(mx);
             const float m_new = fmaxf(m_run[qi], mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             float psum = 0.f;
@@ -300,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
         for (int d = 0; d < DT; ++d) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                if (MASKED && u == 1 && !second_half) continue;
                 const char* va = Vs + u * 4 * VG + vrow_off + d * 32;
                 const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (__attribute__((address_space(3))) i16x4*)(va));

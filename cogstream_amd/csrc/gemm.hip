@@ -565,6 +565,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
         // epilogue of this tile; it runs inside this group's next L interval, i.e. beside the other group's C
         stamp();
         epilogue_wave<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0]);
+        if (tracing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        stamp();
         epilogue_wave<T, EPI>(p.epi, m0 + grp * 128 + 64, n0 + wc * 64, p.M, p.N, lane, acc[1]);
         stamp();
         epi_stores = (WIDE_EPI && (p.N & 31) == 0 && m0 + BM3 <= p.M && n0 + BN3 <= p.N) ? 16 : 0;
@@ -615,14 +617,16 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         (void)hipMemsetAsync(dbuf, 0, 192 * 8, st);
         GemmArgs q = p;
         q.trace = dbuf;
+        q.epi.diag = atoi(getenv("COGS_GEMM_TRACE"));
         hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, q);
         unsigned long long h[192];
         (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
         for (int g = 0; g < 2; ++g) {
             fprintf(stderr, "[gemm trace] EPI=%d M=%d N=%d K=%d group %d:", EPI, p.M, p.N, p.K, g);
-            for (int i = 0; i + 2 < 96 && h[g * 96 + i + 2]; i += 3)
-                fprintf(stderr, " k%llu/e%llu", h[g * 96 + i + 1] - h[g * 96 + i], h[g * 96 + i + 2] - h[g * 96 + i + 1]);
+            for (int i = 0; i + 3 < 96 && h[g * 96 + i + 3]; i += 4)
+                fprintf(stderr, " k%llu/e%llu+%llu", h[g * 96 + i + 1] - h[g * 96 + i], h[g * 96 + i + 2] - h[g * 96 + i + 1],
+                        h[g * 96 + i + 3] - h[g * 96 + i + 2]);
             fprintf(stderr, "\n");
         }
         return;

@@ -40,6 +40,7 @@ struct EpiArgs {
     int rope_pairs;
     int rope_cols;
     int head_dim;
+    int diag;                   // diagnostics only (COGS_GEMM_TRACE=2: lean path skips its store instructions)
 };
 
 // (cos, sin) of the two rotary pairs pi, pi+1 of row m, from either table format
@@ -357,7 +358,8 @@ __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int
                 const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
                 const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                *reinterpret_cast<u32x4*>(cbase + mi * c_row16 + c_lane + 64 * pr) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                if (p.diag != 2) *reinterpret_cast<u32x4*>(cbase + mi * c_row16 + c_lane + 64 * pr) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                else asm volatile("" ::"v"(s0), "v"(s1));
             }
         }
     }
@@ -395,6 +397,7 @@ inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {
     e->rope_cos = g.rope_cos; e->rope_sin = g.rope_sin;
     e->rope_pairs = g.head_dim / 2; e->rope_cols = g.rope_cols;
     e->head_dim = g.head_dim > 0 ? g.head_dim : 4;
+    e->diag = 0;
     return COGS_OK;
 }
 

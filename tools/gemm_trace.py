@@ -3,7 +3,7 @@
 import os
 import sys
 
-os.environ["COGS_GEMM_TRACE"] = "1"
+os.environ.setdefault("COGS_GEMM_TRACE", "1")
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
