@@ -8,8 +8,11 @@
 One STEP = one pass of the encoder stage over the clip with pixel_values already resident in HBM:
 cogs_vit_encode (patch-embed GEMM, 27 x {LN, QKV GEMM+RoPE, per-frame attention, out-proj, LN, MLP},
 post-LN + 2x2 merge) + cogs_project -- SURVEY.md section 8(d) "frames/sec encoded = T / t(A1..A7)".
-N > 1 (strong scaling, the clip's frames are sharded): each rank encodes T/N frames, one RCCL all-gather
-reassembles the [M,1152] visual tokens, every rank then runs the projector; time = max over ranks.
+N > 1: the clip's frames are sharded, rank r encodes and projects its contiguous slice, ONE RCCL all-gather
+reassembles the [M,3584] visual tokens in frame order on every rank (the LLM rank needs them all); time = max
+over ranks. Default `--scaling weak`: the clip grows with N (64 frames per GPU: N = 4 is BASELINE.json's
+256-frame configs[2] clip), so per-GPU work is the N = 1 workload; `--scaling strong` shards the 64-frame clip
+itself (8 frames per GPU at N = 8). The Qwen2 section, the pre-processing line and the CPU baseline are N = 1 only.
 
 The same JSON line also carries, measured after the timed steps on rank 0:
   answer_tokens_per_s   greedy decode rate of the Qwen2-7B path (prefill of the full ~15k-token
@@ -58,6 +61,8 @@ def main() -> None:
     ap.add_argument("--no-llm", action="store_true", help="skip the Qwen2 prefill/decode section")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--clip", default="noise", choices=["noise", "drift"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = --frames per GPU (clip of frames*N), strong = --frames in total")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -68,11 +73,19 @@ def main() -> None:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     import torch.distributed as dist
 
+    # rehearsal on a one-GPU box only: COGS_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo (the
+    # all-gather then stages through host memory, see parallel.gather_tokens); never set by the driver
+    rehearsal = os.environ.get("COGS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from cogstream_amd import _lib as L
     from cogstream_amd import processing
@@ -81,24 +94,42 @@ def main() -> None:
                                        random_vit_state)
 
     vcfg, lcfg = VisionConfig(), LlmConfig()
-    T = args.frames
-    assert T % world == 0, "frames must divide over the ranks"
+    from cogstream_amd.parallel import frame_shards, gather_tokens
+    from cogstream_amd.preprocess_gpu import preprocess_videos_gpu
+    weak = world > 1 and args.scaling == "weak"
+    T = args.frames * world if weak else args.frames          # frames of the whole clip
+    f_lo, f_hi = frame_shards(T, world)[rank]
+    t_loc = f_hi - f_lo
 
-    # ---- synthetic clip -> pixel_values (host preprocessing is outside the timed region) ----
-    frames, timestamps = processing.synthetic_clip(T, kind=args.clip)
+    # ---- synthetic clip -> pixel_values, outside the timed region. Each rank makes only its own frames (clip
+    # content is per 64-frame chunk, so the N = 1 clip is chunk 0) and pre-processes them on its GPU; at N = 1
+    # the host PIL path runs too and the two results are compared bit for bit. ----
+    chunks = sorted({f // 64 for f in range(f_lo, f_hi)})
+    parts = {c: processing.synthetic_clip(64, kind=args.clip, clip_idx=c)[0] for c in chunks}
+    frames = np.stack([parts[f // 64][f % 64] for f in range(f_lo, f_hi)])
+    torch.zeros(1).to(dev)    # context / allocator warm-up, so that h2d_ms is the copy
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    feats = processing.preprocess_videos([frames], merge_size=2)
-    t_host_pre = time.perf_counter() - t0
-    t, gh, gw = (int(v) for v in feats["grid_sizes"][0])
+    dframes = torch.from_numpy(frames).to(dev)
+    torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - t0) * 1e3
+    # token budget: the processor's 16384 visual tokens per 64 frames (cfg2 -> 308x588 per frame), scaled with the
+    # shard so that every rank picks the same per-frame size
+    feats = preprocess_videos_gpu([dframes], merge_size=2, max_tokens=16384 * t_loc // 64)
+    pix = feats["pixel_values"]   # bf16 on the GPU (evaluate/answer_generate.py:70 casts pixel_values to bf16)
+    _, gh, gw = (int(v) for v in feats["grid_sizes"][0])
+    grid_loc = torch.tensor([[t_loc, gh, gw]])
     per_frame = gh * gw
     P = per_frame // 4
     n_patches, m_tokens = T * per_frame, T * P
-    pix_all = torch.from_numpy(feats["pixel_values"])
-    from cogstream_amd.parallel import gather_tokens, shard_video
-    t_loc = T // world
-    pix_loc, grid_loc = shard_video(pix_all, (T, gh, gw), rank, world)
-    pix = pix_loc.to(dev, torch.bfloat16)  # evaluate/answer_generate.py:70 casts pixel_values to bf16
     merge = torch.tensor([2])
+    pix_all = None
+    if world == 1:
+        t0 = time.perf_counter()
+        host = processing.preprocess_videos([frames], merge_size=2)
+        t_host_pre = time.perf_counter() - t0
+        pix_all = torch.from_numpy(host["pixel_values"])
+        same_as_host = bool(torch.equal(pix.cpu(), pix_all.bfloat16()))
 
     # ---- weights (random, real dimensions) ----
     vit_state = random_vit_state(vcfg, seed=0, device=dev, dtype=torch.bfloat16)
@@ -108,8 +139,7 @@ def main() -> None:
     del vit_state
 
     def step():
-        tok = enc(pix, grid_loc, merge)
-        return proj(gather_tokens(tok, (T, gh, gw), 2, world))
+        return gather_tokens(proj(enc(pix, grid_loc, merge)), (T, gh, gw), 2, world)
 
     def barrier():
         if world > 1:
@@ -134,12 +164,15 @@ def main() -> None:
     out = {
         "metric": "frames/sec encoded + answer tokens/sec, 64-frame clip, VideoLLaMA3-7B",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"cfg2: {T}x480x854 '{args.clip}' clip -> {gh * 14}x{gw * 14}, {n_patches} patches, "
-                               f"{m_tokens} visual tokens; ViT(1152x27, hd72)+projector(3584); random-init weights",
-                   "frames": T, "patches": n_patches, "visual_tokens": m_tokens,
-                   "parallelism": f"frames sharded over {world} GPU(s) + all-gather" if world > 1 else "single GPU"},
+        "config": {"workload": f"{'cfg2' if T == 64 else 'cfg3-style'}: {T}x480x854 '{args.clip}' clip -> {gh * 14}x{gw * 14}, "
+                               f"{n_patches} patches, {m_tokens} visual tokens; ViT(1152x27, hd72)+projector(3584); "
+                               f"random-init weights",
+                   "frames": T, "frames_per_gpu": t_loc, "patches": n_patches, "visual_tokens": m_tokens,
+                   "parallelism": (f"frames sharded over {world} GPUs ({t_loc} each), encode+project per rank, one RCCL "
+                                   f"all-gather of the [M,3584] tokens") if world > 1 else "single GPU"},
     }
 
     # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events around every launch ----
@@ -149,11 +182,10 @@ def main() -> None:
     cnt = (C.c_int * 4)()
     barrier()
     L.check(L.lib.cogs_profile_begin(h.h))
-    tok = enc(pix, grid_loc, merge)
-    proj(gather_tokens(tok, (T, gh, gw), 2, world))
+    gather_tokens(proj(enc(pix, grid_loc, merge)), (T, gh, gw), 2, world)
     L.check(L.lib.cogs_profile_end(h.h, L.current_stream(), ms, cnt))
     if rank == 0:
-        n_loc, m_proj = t_loc * per_frame, (m_tokens if world > 1 else t_loc * P)
+        n_loc, m_proj = t_loc * per_frame, t_loc * P
         gflops = vit_gemm_flops(n_loc, m_proj, vcfg, lcfg.hidden_size)
         gemm_ms, gemm_n = float(ms[0]), int(cnt[0])
         ach = gflops / (gemm_ms * 1e-3) / 1e12
@@ -175,10 +207,10 @@ def main() -> None:
                                "other": round(float(ms[3]), 2)}
         out["attention_tflops"] = round(vit_attn_flops(t_loc, per_frame, vcfg) / (attn_ms * 1e-3) / 1e12, 1)
         total_flops = vit_gemm_flops(n_patches, m_tokens, vcfg, lcfg.hidden_size) + vit_attn_flops(T, per_frame, vcfg)
-        out["encoder_tflops"] = round(total_flops / (ms_per_step * 1e-3) / 1e12, 1)
+        out["encoder_tflops"] = round(total_flops / (ms_per_step * 1e-3) / 1e12, 1)   # whole job, all GPUs
 
     # ---- Qwen2-7B: prefill of the interleaved prompt + greedy decode (rank 0; other ranks wait) ----
-    if rank == 0 and not args.no_llm:
+    if rank == 0 and world == 1 and not args.no_llm:
         from cogstream_amd.llm import Qwen2Engine
         enc.handle._ws.pop("vit", None)  # release the encoder workspace
         torch.cuda.empty_cache()
@@ -217,23 +249,15 @@ def main() -> None:
         del eng, cache
         torch.cuda.empty_cache()
 
-    # ---- GPU pre-processing of the same clip (uint8 frames -> pixel_values) ----
+    # ---- GPU pre-processing of the clip (uint8 frames -> pixel_values) ----
     if rank == 0 and world == 1:
-        from cogstream_amd.preprocess_gpu import preprocess_videos_gpu
-        t0 = time.perf_counter()
-        dframes = torch.from_numpy(frames).to(dev)
-        torch.cuda.synchronize()
-        h2d_ms = (time.perf_counter() - t0) * 1e3
-        got = preprocess_videos_gpu([dframes])
-        same = bool(torch.equal(got["pixel_values"], pix))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(5):
             preprocess_videos_gpu([dframes])
         torch.cuda.synchronize()
         out["preprocess"] = {"gpu_ms": round((time.perf_counter() - t0) / 5 * 1e3, 3), "h2d_ms": round(h2d_ms, 3),
-                             "host_pil_ms": round(t_host_pre * 1e3, 1), "equal_to_host_path": same}
-        del dframes, got
+                             "host_pil_ms": round(t_host_pre * 1e3, 1), "equal_to_host_path": same_as_host}
 
     # ---- CPU baseline: the oracle on host cores, bounded sample (rank 0, N = 1) ----
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -532,6 +532,11 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
             g.bias = L.qkv_b; g.M = S; g.N = qd; g.K = H;
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = qd_q + kvd; g.head_dim = hd;
             if (fuse_norm) { g.rms_gamma = L.in_ln; g.rms_eps = w.rms_eps; }
+            if (kv && S == 1) {   // single-token decode: the GEMV writes the new K / V row straight into the cache
+                g.kv_k = (char*)kv->k + (((size_t)l * kv->max_len) + pos0) * kvd * es;
+                g.kv_v = (char*)kv->v + (((size_t)l * kv->max_len) + pos0) * kvd * es;
+                g.kv_col0 = qd_q; g.kv_dim = kvd;
+            }
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         const char* kp = (const char*)qkv + (size_t)qd_q * es;
@@ -540,8 +545,11 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
         if (kv) {
             char* kc = (char*)kv->k + ((size_t)l * kv->max_len) * kvd * es;
             char* vc = (char*)kv->v + ((size_t)l * kv->max_len) * kvd * es;
-            { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_kv_append(st, dt, kp, vp, qd, kc + (size_t)pos0 * kvd * es,
-                                                                vc + (size_t)pos0 * kvd * es, kvd, S, kvd)); }
+            if (S != 1) {
+                PROF(COGS_PROF_OTHER);
+                COGS_TRY(cogs_k_kv_append(st, dt, kp, vp, qd, kc + (size_t)pos0 * kvd * es, vc + (size_t)pos0 * kvd * es,
+                                          kvd, S, kvd));
+            }
             kp = kc; vp = vc; ldkv = kvd;
         }
         {

@@ -3,8 +3,8 @@
 // Replaces the M = 1 case of the Qwen2 linears during generation (transformers GenerationMixin
 // decode steps behind model/cogreasoner_chat.py:802-807). HBM-bound: every weight byte is read
 // exactly once, straight into registers (no LDS round trip: nothing is shared between waves);
-// each wave owns 4 consecutive output rows (one epilogue group: bias / rope pair / swiglu pair /
-// residual), lanes stride over K in 16-byte chunks, 8 independent 16-B loads in flight per lane
+// each wave owns 4 (or 2) consecutive output rows (whole epilogue groups: bias / rope pair / swiglu
+// pair / residual), lanes stride over K in 16-byte chunks, 8 independent 16-B loads in flight per lane
 // per step; x is re-read from L2. fp32 accumulation, 64-lane butterfly per row.
 #include "common.h"
 #include "kernels.h"
@@ -18,6 +18,7 @@ struct GemvArgs {
     int N, K;
     const void* rms_gamma;    // != null: x is RMS-normalised on the fly (Qwen2RMSNorm fused into the GEMV)
     float rms_eps;
+    char* kv_k; char* kv_v; int kv_col0, kv_dim;   // != null: columns >= kv_col0 are the new K / V cache row
     EpiArgs epi;
 };
 
@@ -37,17 +38,52 @@ __device__ __forceinline__ void rms_apply(float (&x)[E], const T* gamma, float r
     }
 }
 
+// epilogue of 2 consecutive output columns n, n+1 (one rotary / SwiGLU pair): same arithmetic as epilogue4
 template <typename T>
+__device__ __forceinline__ void epilogue2(const EpiArgs& p, int n, float v0, float v1) {
+    const T* bias = reinterpret_cast<const T*>(p.bias);
+    if (bias) {
+        if constexpr (sizeof(T) == 2) { v0 += bf2f(bias[n]); v1 += bf2f(bias[n + 1]); }
+        else { v0 += bias[n]; v1 += bias[n + 1]; }
+    }
+    if (p.rope_cos && n < p.rope_cols) {
+        const int pi = (n % p.head_dim) >> 1;
+        float c, sn;
+        if (p.rope_sin) { c = p.rope_cos[pi]; sn = p.rope_sin[pi]; }
+        else { c = p.rope_cos[2 * pi]; sn = p.rope_cos[2 * pi + 1]; }
+        const float r0 = v0 * c - v1 * sn;
+        const float r1 = v1 * c + v0 * sn;
+        v0 = r0; v1 = r1;
+    }
+    if (p.act == COGS_ACT_GELU_TANH) { v0 = gelu_tanh_f(v0); v1 = gelu_tanh_f(v1); }
+    else if (p.act == COGS_ACT_GELU_ERF) { v0 = gelu_erf_f(v0); v1 = gelu_erf_f(v1); }
+    else if (p.act == COGS_ACT_SWIGLU) {
+        st_f<T>(reinterpret_cast<T*>(p.C) + (n >> 1), silu_f(v0) * v1);
+        return;
+    }
+    if (p.R) {
+        const T* r = reinterpret_cast<const T*>(p.R);
+        if constexpr (sizeof(T) == 2) { v0 += bf2f(r[n]); v1 += bf2f(r[n + 1]); }
+        else { v0 += r[n]; v1 += r[n + 1]; }
+    }
+    if (p.out_f32) { reinterpret_cast<float*>(p.C)[n] = v0; reinterpret_cast<float*>(p.C)[n + 1] = v1; }
+    else { st_f<T>(reinterpret_cast<T*>(p.C) + n, v0); st_f<T>(reinterpret_cast<T*>(p.C) + n + 1, v1); }
+}
+
+// R output rows per wave (4: big N; 2: N so small that 4 rows per wave would leave CUs without enough bytes in
+// flight -- the 3584-row o/down projections launched 224 workgroups on 256 CUs and ran at 2-5 TB/s), U chunks of
+// 16 bytes per row in flight per lane (R*U = 8 independent loads, kept raw until used).
+template <typename T, int R, int U>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
     const int lane = threadIdx.x & 63;
-    const int n = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    const int n = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (n >= p.N) return;
     const int nch = p.K / EPC;
     const T* x = reinterpret_cast<const T*>(p.x);
-    const T* w[4];
+    const T* w[R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w[r] = reinterpret_cast<const T*>(p.W + (long)min(n + r, p.N - 1) * p.ldw);
+    for (int r = 0; r < R; ++r) w[r] = reinterpret_cast<const T*>(p.W + (long)min(n + r, p.N - 1) * p.ldw);
     const T* gam = reinterpret_cast<const T*>(p.rms_gamma);
     float rstd = 1.f;
     if (gam) {
@@ -63,42 +99,66 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
         ss = wave_sum(ss);
         rstd = rsqrtf(ss / (float)p.K + p.rms_eps);
     }
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int ch = lane;
-    for (; ch + 64 < nch; ch += 128) {
-        float xa[EPC], xb[EPC], wa[4][EPC], wb[4][EPC];
+    auto to_f = [](const u32x4& raw, float (&o)[EPC]) {
+        if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if constexpr (sizeof(T) == 2) { ld8_f<T>(w[r] + ch * EPC, wa[r]); ld8_f<T>(w[r] + (ch + 64) * EPC, wb[r]); }
-            else { f32x4 t0 = ld4_f<T>(w[r] + ch * EPC), t1 = ld4_f<T>(w[r] + (ch + 64) * EPC);
-                   for (int e = 0; e < 4; ++e) { wa[r][e] = t0[e]; wb[r][e] = t1[e]; } }
+            for (int i = 0; i < 4; ++i) { o[2 * i] = bf_lo(raw[i]); o[2 * i + 1] = bf_hi(raw[i]); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(raw[i]);
         }
-        if constexpr (sizeof(T) == 2) { ld8_f<T>(x + ch * EPC, xa); ld8_f<T>(x + (ch + 64) * EPC, xb); }
-        else { f32x4 t0 = ld4_f<T>(x + ch * EPC), t1 = ld4_f<T>(x + (ch + 64) * EPC);
-               for (int e = 0; e < 4; ++e) { xa[e] = t0[e]; xb[e] = t1[e]; } }
-        if (gam) { rms_apply<T, EPC>(xa, gam + ch * EPC, rstd); rms_apply<T, EPC>(xb, gam + (ch + 64) * EPC, rstd); }
+    };
+    float acc[R];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    int ch = lane;
+    for (; ch + 64 * (U - 1) < nch; ch += 64 * U) {
+        u32x4 wr[U][R], xr[U];
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) { acc[r] += wa[r][e] * xa[e]; acc[r] += wb[r][e] * xb[e]; }
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) wr[u][r] = *reinterpret_cast<const u32x4*>(w[r] + (ch + 64 * u) * EPC);
+#pragma unroll
+        for (int u = 0; u < U; ++u) xr[u] = *reinterpret_cast<const u32x4*>(x + (ch + 64 * u) * EPC);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float xa[EPC];
+            to_f(xr[u], xa);
+            if (gam) rms_apply<T, EPC>(xa, gam + (ch + 64 * u) * EPC, rstd);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float wa[EPC];
+                to_f(wr[u][r], wa);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[r] += wa[e] * xa[e];
+            }
+        }
     }
     for (; ch < nch; ch += 64) {
-        float xa[EPC], wa[EPC];
-        if constexpr (sizeof(T) == 2) ld8_f<T>(x + ch * EPC, xa);
-        else { f32x4 t0 = ld4_f<T>(x + ch * EPC); for (int e = 0; e < 4; ++e) xa[e] = t0[e]; }
+        u32x4 wr[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wr[r] = *reinterpret_cast<const u32x4*>(w[r] + ch * EPC);
+        float xa[EPC];
+        to_f(*reinterpret_cast<const u32x4*>(x + ch * EPC), xa);
         if (gam) rms_apply<T, EPC>(xa, gam + ch * EPC, rstd);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if constexpr (sizeof(T) == 2) ld8_f<T>(w[r] + ch * EPC, wa);
-            else { f32x4 t0 = ld4_f<T>(w[r] + ch * EPC); for (int e = 0; e < 4; ++e) wa[e] = t0[e]; }
+        for (int r = 0; r < R; ++r) {
+            float wa[EPC];
+            to_f(wr[r], wa);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) acc[r] += wa[e] * xa[e];
         }
     }
-    f32x4 v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = wave_sum(acc[r]);
-    if (lane == 0) epilogue4<T>(p.epi, 0, n, v);
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+        EpiArgs e = p.epi;
+        if (p.kv_k && n >= p.kv_col0)   // region boundaries are multiples of 4: a wave's columns lie in one region
+            e.C = (n < p.kv_col0 + p.kv_dim) ? p.kv_k - (long)p.kv_col0 * sizeof(T)
+                                             : p.kv_v - (long)(p.kv_col0 + p.kv_dim) * sizeof(T);
+        if constexpr (R == 4) epilogue4<T>(e, 0, n, f32x4{acc[0], acc[1], acc[2], acc[3]});
+        else epilogue2<T>(e, n, acc[0], acc[1]);
+    }
 }
 
 }  // namespace
@@ -113,8 +173,18 @@ int cogs_k_gemv(hipStream_t st, const CogsGemm& g) {
     p.W = (const char*)g.W; p.ldw = g.ldw * es;
     p.N = g.N; p.K = g.K;
     p.rms_gamma = g.rms_gamma; p.rms_eps = g.rms_eps;
-    const int grid = (g.N / 4 + 3) / 4;
-    if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL(gemv_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(gemv_kernel<float>, dim3(grid), dim3(256), 0, st, p);
+    p.kv_k = (char*)g.kv_k; p.kv_v = (char*)g.kv_v; p.kv_col0 = g.kv_col0; p.kv_dim = g.kv_dim;
+    if (g.kv_k && (g.kv_col0 % 4 || g.kv_dim % 4 || g.out_f32 || g.act == COGS_ACT_SWIGLU)) return COGS_E_INVALID;
+    // 4 rows per wave when that still gives every CU several workgroups, else 2 (N % 4 == 0 keeps pairs whole)
+    const bool small_n = g.N / 16 < 1024;
+    if (small_n) {
+        const int grid = (g.N / 2 + 3) / 4;
+        if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL((gemv_kernel<bf16_t, 2, 4>), dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemv_kernel<float, 2, 4>), dim3(grid), dim3(256), 0, st, p);
+    } else {
+        const int grid = (g.N / 4 + 3) / 4;
+        if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL((gemv_kernel<bf16_t, 4, 2>), dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemv_kernel<float, 4, 2>), dim3(grid), dim3(256), 0, st, p);
+    }
     return COGS_LAUNCH_CHECK();
 }

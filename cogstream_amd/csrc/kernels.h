@@ -27,6 +27,9 @@ struct CogsGemm {
     int force_small_tile = 0;                // testing: always use the 128x128 kernel
     const void* rms_gamma = nullptr;         // M == 1 only: RMS-normalise A on the fly with this weight
     float rms_eps = 0.f;
+    // M == 1 only: output columns [kv_col0, kv_col0 + kv_dim) go to kv_k[0..kv_dim), the next kv_dim to kv_v
+    // (single-token decode writes the new K/V row straight into the cache; no kv_append launch)
+    void* kv_k = nullptr; void* kv_v = nullptr; int kv_col0 = 0; int kv_dim = 0;
 };
 int cogs_k_gemm(hipStream_t st, const CogsGemm& g);
 

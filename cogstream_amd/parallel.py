@@ -38,6 +38,10 @@ def gather_tokens(local_tokens: torch.Tensor, grid_size: Tuple[int, int, int], m
     t, gh, gw = (int(v) for v in grid_size)
     ppf = (gh // merge_size) * (gw // merge_size)
     shards = frame_shards(t, world)
+    if local_tokens.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no device all-gather: stage through host memory (CPU tests and one-GPU rehearsals only;
+        # on a node the backend is nccl = RCCL and the tensors never leave HBM / xGMI)
+        return gather_tokens(local_tokens.cpu(), grid_size, merge_size, world, group).to(local_tokens.device)
     if all(e - b == shards[0][1] - shards[0][0] for b, e in shards):
         out = torch.empty(t * ppf, local_tokens.shape[1], dtype=local_tokens.dtype, device=local_tokens.device)
         dist.all_gather_into_tensor(out, local_tokens.contiguous(), group=group)
