@@ -21,6 +21,7 @@
 // fp32 / generic kernel: one wave per (query row, head), two passes; parity mode only.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -58,13 +59,17 @@ __device__ __forceinline__ float colgroup_max(float x) {
 
 __device__ __forceinline__ int k_swz(int row) { return (row & 3) | (((row >> 3) & 3) << 2); }
 
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
+// NQ = 16-row query sub-tiles per wave: 2 -> 4 waves x 32 rows (256 threads, 2 waves per SIMD at 2 workgroups per CU);
+// 1 -> 8 waves x 16 rows (512 threads): half the accumulator / score registers per wave, so twice the waves per
+// SIMD overlap each other's MFMA, VALU and LDS phases, at the price of reading every K/V fragment for 16 rows only.
+template <int HD, int NQ>
+__global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : 2) void attn_fwd_bf16_kernel(AttnArgs p) {
+    constexpr int NT = 128 * (4 / NQ);        // threads per workgroup (always 128 query rows)
     constexpr int KS = (HD + 31) / 32;        // QK^T k-steps
     constexpr int DT = (HD + 15) / 16;        // PV d-tiles
     constexpr int CH = HD / 8;                // 16-byte chunks per K/V row
     constexpr int NCH = 64 * CH;
-    constexpr int PER = (NCH + 255) / 256;
+    constexpr int PER = (NCH + NT - 1) / NT;
     constexpr int VS = (HD > 80) ? 288 : 160; // V row stride, == 32*odd bytes
     constexpr int VG = 8 * VS + 128;          // stride of a group of 8 V rows
     constexpr int K_LDS = 64 * 256;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
 
     // zero the pad columns once (staging never writes them)
     if (HD % 32 != 0) {
-        for (int id = tid; id < 64 * (16 - CH); id += 256) {
+        for (int id = tid; id < 64 * (16 - CH); id += NT) {
             const int row = id / (16 - CH), c = CH + id % (16 - CH);
             *reinterpret_cast<u32x4*>(Ks + row * 256 + ((c ^ k_swz(row)) << 4)) = u32x4{0, 0, 0, 0};
         }
@@ -99,23 +104,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
     // i.e. the softmax denominator comes out of the PV MFMAs for free (and is rescaled with O)
     constexpr bool SUM_IN_V = (HD % 16 != 0);
     if (SUM_IN_V) {
-        for (int row = tid; row < 64; row += 256)
+        for (int row = tid; row < 64; row += NT)
             *reinterpret_cast<u32x4*>(Vs + (row >> 3) * VG + (row & 7) * VS + CH * 16) = u32x4{0x00003f80u, 0, 0, 0};
     }
 
     // Q fragments (B operand of S^T = K.Q^T): lane (q = li, g) holds Q[q][32s + 8g + j]
-    bf16x8 qf[2][KS];
-    int qrow[2], qhead[2];
-    bool qok[2];
+    bf16x8 qf[NQ][KS];
+    int qrow[NQ], qhead[NQ];
+    bool qok[NQ];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
+    for (int qi = 0; qi < NQ; ++qi) {
         if (p.gqa_pack) {
             // one query token; column li of sub-tile 0 of wave 0 is q-head kvh*gsz + li
             qrow[qi] = q0;
             qhead[qi] = kvh * gsz + li;
             qok[qi] = (wid == 0 && qi == 0 && li < gsz);
         } else {
-            qrow[qi] = q0 + wid * 32 + qi * 16 + li;
+            qrow[qi] = q0 + wid * (16 * NQ) + qi * 16 + li;
             qhead[qi] = blockIdx.y;
             qok[qi] = qrow[qi] < qe;
         }
@@ -135,16 +140,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
     const int t_begin = (int)((long)nt_all * split / p.nsplit);
     const int nt = (int)((long)nt_all * (split + 1) / p.nsplit);
 
-    f32x4 oacc[DT][2];
+    f32x4 oacc[DT][NQ];
 #pragma unroll
-    for (int d = 0; d < DT; ++d) { oacc[d][0] = f32x4{0, 0, 0, 0}; oacc[d][1] = f32x4{0, 0, 0, 0}; }
-    float m_run[2] = {-INFINITY, -INFINITY};
-    float l_run[2] = {0.f, 0.f};
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) oacc[d][qi] = f32x4{0, 0, 0, 0};
+    float m_run[NQ], l_run[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) { m_run[qi] = -INFINITY; l_run[qi] = 0.f; }
 
-    int blo[2] = {0, 0}, bhi[2] = {0, 0};
+    int blo[NQ], bhi[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) { blo[qi] = 0; bhi[qi] = 0; }
     if (p.row_lo) {
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
+        for (int qi = 0; qi < NQ; ++qi)
             if (qok[qi]) { blo[qi] = p.row_lo[qrow[qi]]; bhi[qi] = p.row_hi[qrow[qi]]; }
     }
 
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
     bool st_ok[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int id = tid + i * 256;
+        const int id = tid + i * NT;
         st_ok[i] = id < NCH;
         const int row = st_ok[i] ? id / CH : 0, c = st_ok[i] ? id % CH : 0;
         st_row[i] = row;
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
         if (kbase + 64 <= ke) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                if (i + 1 < PER || NCH % 256 == 0 || st_ok[i]) {
+                if (i + 1 < PER || NCH % NT == 0 || st_ok[i]) {
                     kreg[i] = *reinterpret_cast<const u32x4*>(kb + k_goff[i]);
                     vreg[i] = *reinterpret_cast<const u32x4*>(vb + v_goff[i]);
                 }
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
     auto write_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            if (i + 1 < PER || NCH % 256 == 0 || st_ok[i]) {
+            if (i + 1 < PER || NCH % NT == 0 || st_ok[i]) {
                 *reinterpret_cast<u32x4*>(Ks + k_loff[i]) = kreg[i];
                 *reinterpret_cast<u32x4*>(Vs + v_loff[i]) = vreg[i];
             }
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
     // V transposed read: lane i of a 16-lane group supplies row k0 + (i>>2), cols d0 + 4(i&3)
     const int vrow_off = g * VG + (li >> 2) * VS + (li & 3) * 8;
 
-    const bool wave_active = p.gqa_pack ? (wid == 0) : (q0 + wid * 32 < qe);   // wave-uniform
+    const bool wave_active = p.gqa_pack ? (wid == 0) : (q0 + wid * (16 * NQ) < qe);   // wave-uniform
     if (t_begin < nt) load_tile(t_begin);
     // one K/V tile; MASKED is a compile-time tag: interior tiles run a compare-free softmax body, only the
     // tiles that touch the key-range end, the causal diagonal or the bias mode evaluate masks. (A run-time
@@ -223,12 +233,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
         // ragged last key tile: when the second 32-key half is entirely past the range its MFMAs are skipped
         // (wave-uniform; P of that half would be exactly zero)
         const bool second_half = !MASKED || kbase + 32 < kend;
-        f32x4 sacc[4][2];
+        f32x4 sacc[4][NQ];
 #pragma unroll
         for (int ut = 0; ut < 4; ++ut) {
             if (MASKED && ut >= 2 && !second_half) {
-                sacc[ut][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                sacc[ut][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) sacc[ut][qi] = f32x4{0.f, 0.f, 0.f, 0.f};
                 continue;
             }
             const int krow = 32 * (ut >> 1) + 4 * (ut & 1) + krow0;
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
             for (int s = 0; s < KS; ++s) {
                 const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + krow * 256 + (((4 * s + g) ^ ksw) << 4));
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi)
+                for (int qi = 0; qi < NQ; ++qi)
                     sacc[ut][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, kf), qf[qi][s],
                         s == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[ut][qi], 0, 0, 0);   // C = 0 is an inline constant
@@ -247,9 +257,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
         // online softmax; lane holds keys kbase + 32u + 8g + 4t + reg of query column li.
         // Masking (key range, causal diagonal, same-segment bias) is only evaluated on tiles that need it:
         // the test is block-uniform, so interior tiles run a compare-free body (max, fma, v_exp, add).
-        bf16x8 pf[2][2];
+        bf16x8 pf[2][NQ];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
+        for (int qi = 0; qi < NQ; ++qi) {
             float sv[4][4];
             float mx = -INFINITY;
             if constexpr (MASKED) {
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
                 w[0] = l2[0]; w[1] = l2[1]; w[2] = h2[0]; w[3] = h2[1];
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, w);
 #pragma unroll
-                for (int qi = 0; qi < 2; ++qi)
+                for (int qi = 0; qi < NQ; ++qi)
                     oacc[d][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][qi], oacc[d][qi], 0, 0, 0);
             }
         }
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs p) {
 
     bf16_t* Op = reinterpret_cast<bf16_t*>(p.O);
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
+    for (int qi = 0; qi < NQ; ++qi) {
         float l = l_run[qi];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
@@ -535,10 +545,17 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
         }
         if (a.q_len == 1 && a.hq / a.hkv <= 16 && !a.cu_seqlens) { p.gqa_pack = 1; gy = a.hkv; }
         dim3 grid(qtiles * p.nsplit, gy, nseg);
-        if (a.head_dim == 72)
-            hipLaunchKernelGGL(attn_fwd_bf16_kernel<72>, grid, dim3(256), 0, st, p);
-        else
-            hipLaunchKernelGGL(attn_fwd_bf16_kernel<128>, grid, dim3(256), 0, st, p);
+        static const int env_nq = getenv("COGS_ATTN_NQ") ? atoi(getenv("COGS_ATTN_NQ")) : 0;
+        // 8 waves x 16 rows: measured faster for hd 128 (no spills, 4 waves per SIMD: causal prefill 2.58 -> 2.29 ms
+        // at 15k tokens), slower for hd 72 (0.49 -> 0.52 ms: its fragment reads make the LDS the busiest unit)
+        const bool light = env_nq ? env_nq == 1 : (a.head_dim == 128);
+        if (a.head_dim == 72) {
+            if (light && !p.gqa_pack) hipLaunchKernelGGL((attn_fwd_bf16_kernel<72, 1>), grid, dim3(512), 0, st, p);
+            else hipLaunchKernelGGL((attn_fwd_bf16_kernel<72, 2>), grid, dim3(256), 0, st, p);
+        } else {
+            if (light && !p.gqa_pack) hipLaunchKernelGGL((attn_fwd_bf16_kernel<128, 1>), grid, dim3(512), 0, st, p);
+            else hipLaunchKernelGGL((attn_fwd_bf16_kernel<128, 2>), grid, dim3(256), 0, st, p);
+        }
         if (p.nsplit > 1)
             hipLaunchKernelGGL(attn_combine_kernel, dim3(a.q_len, a.hq), dim3(256), 0, st, p.part_o, p.part_ml, p.nsplit,
                                a.q_len, a.hq, a.head_dim, (bf16_t*)a.O, a.ldo);
