@@ -22,7 +22,14 @@ def infer(conversation, model, processor, select=None, if_visual=None, max_new_t
     inputs = {k: (v.to(model.device) if isinstance(v, torch.Tensor) and k in ("pixel_values",) else v) for k, v in inputs.items()}
     if "pixel_values" in inputs and model.dtype == torch.bfloat16:
         inputs["pixel_values"] = inputs["pixel_values"].to(dtype=torch.bfloat16)   # :70
+    # :71-73 -- the selection stage runs under the "language_module" adapter, the answer under "full_module";
+    # a model without adapters (none have been released) runs both on the base weights
+    has = getattr(model, "_adapters", {})
+    if "language_module" in has:
+        model.set_adapter("language_module")
     inputs = model.qa_selection(**inputs, mode="FCC", select_gt=select, if_visual=if_visual)
+    if "full_module" in has:
+        model.set_adapter("full_module")
     output_ids, selection = model.generate(**inputs, max_new_tokens=max_new_tokens, **gen_kwargs)
     response = processor.batch_decode(output_ids, skip_special_tokens=True)[0].strip()
     return response, selection

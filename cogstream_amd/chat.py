@@ -140,6 +140,30 @@ class CogReasoner:
         self.all_timestamps: Optional[torch.Tensor] = None
         self.last_debug: Dict[str, object] = {}
         self.cosine_override: Optional[Sequence[float]] = None
+        self._adapters: Dict[str, tuple] = {"base": (llm, projector)}
+        self.active_adapter = "base"
+
+    # ------------------------------------------------------------------ adapters
+    # The peft surface evaluate/answer_generate.py uses (:71-73 set_adapter, :181-182 from_pretrained /
+    # load_adapter): an adapter here is a merged copy of the Qwen2 (and projector) weights -- weights.merge_lora --
+    # so switching re-points the engine and costs no arithmetic.
+    def add_adapter(self, adapter_name: str, llm: Qwen2Engine, projector: Optional[Projector] = None) -> None:
+        self._adapters[adapter_name] = (llm, projector if projector is not None else self._adapters["base"][1])
+
+    def load_adapter(self, llm_state, proj_state, lora_state, adapter_name: str, lora_alpha: float = 16.0) -> None:
+        """llm_state / proj_state: the BASE weights in HF layout (tensors already on the device are shared, not
+        copied, where the adapter does not touch them); lora_state: peft adapter_model state dict"""
+        from .weights import merge_lora
+        ml, mp = merge_lora(llm_state, proj_state, lora_state, self.config, lora_alpha)
+        llm = Qwen2Engine(ml, self.config, dtype=self.dtype, device=self.device)
+        proj = Projector(mp, dtype=self.dtype, device=self.device) if mp is not None else None
+        self.add_adapter(adapter_name, llm, proj)
+
+    def set_adapter(self, adapter_name: str) -> None:
+        if adapter_name not in self._adapters:
+            raise ValueError(f"Adapter {adapter_name} not found.")   # peft's wording
+        self.llm, self.mm_projector = self._adapters[adapter_name]
+        self.active_adapter = adapter_name
 
     # ------------------------------------------------------------------ vision
     def encode_images(self, pixel_values, grid_sizes, merge_sizes) -> torch.Tensor:

@@ -26,6 +26,7 @@ struct cogs_ctx {
     cogs_llm_weights llm{};
     std::vector<cogs_llm_layer> llm_layers;
     float* llm_inv_freq = nullptr;  // device [head_dim/2]
+    int llm_nfreq = 0; float llm_theta = 0.f;
     // host staging kept alive across async copies
     std::vector<int32_t> h_cu, h_lo, h_hi;
     // optional per-kernel-class event profiling (bench/roofline only)
@@ -463,9 +464,14 @@ cogs_status cogs_llm_load(cogs_handle h, const cogs_llm_weights* w) {
     const int nf = w->head_dim / 2;
     std::vector<float> inv(nf);
     for (int i = 0; i < nf; ++i) inv[i] = 1.0f / powf(w->rope_theta, (float)(2 * i) / (float)w->head_dim);
-    if (h->llm_inv_freq) (void)hipFree(h->llm_inv_freq);
-    if (hipMalloc(&h->llm_inv_freq, nf * sizeof(float)) != hipSuccess) return COGS_E_HIP;
-    if (hipMemcpy(h->llm_inv_freq, inv.data(), nf * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return COGS_E_HIP;
+    // re-pointing the handle at another weight set of the same shape (adapter switch) keeps the device table
+    if (!h->llm_inv_freq || h->llm_nfreq != nf || h->llm_theta != w->rope_theta) {
+        if (h->llm_inv_freq) (void)hipFree(h->llm_inv_freq);
+        h->llm_inv_freq = nullptr;
+        if (hipMalloc(&h->llm_inv_freq, nf * sizeof(float)) != hipSuccess) return COGS_E_HIP;
+        if (hipMemcpy(h->llm_inv_freq, inv.data(), nf * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return COGS_E_HIP;
+        h->llm_nfreq = nf; h->llm_theta = w->rope_theta;
+    }
     h->llm_ok = true;
     return COGS_OK;
 }

@@ -34,7 +34,11 @@ class Qwen2Engine:
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.handle = get_handle(self.device)
         self.packed = PackedLlm(state, cfg, dtype, self.device)
-        L.check(L.lib.cogs_llm_load(self.handle.h, C.byref(self.packed.struct)), "cogs_llm_load")
+        self._activate()
+
+    def _activate(self):
+        self.handle.activate("llm", self, lambda: L.check(
+            L.lib.cogs_llm_load(self.handle.h, C.byref(self.packed.struct)), "cogs_llm_load"))
 
     def new_cache(self, max_len: int) -> KVCache:
         return KVCache(self.cfg, max_len, self.dtype, self.device)
@@ -45,6 +49,7 @@ class Qwen2Engine:
     def forward(self, embeds: torch.Tensor, cache: Optional[KVCache] = None, *, want_logits: bool = True,
                 want_pooled: bool = False, want_hidden: bool = False):
         """returns dict(logits fp32 [vocab] | pooled fp32 [H] | hidden [S,H])"""
+        self._activate()
         embeds = embeds.contiguous()
         S = embeds.shape[0]
         ctx = S + (cache.len if cache is not None else 0)

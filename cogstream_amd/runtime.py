@@ -15,6 +15,7 @@ class Handle:
         self._h = C.c_void_p()
         L.check(L.lib.cogs_create(device_index, C.byref(self._h)), "cogs_create")
         self._ws: Dict[str, torch.Tensor] = {}
+        self._active: Dict[str, object] = {}   # which packed weight set ("vit" / "proj" / "llm") the handle points at
 
     @property
     def h(self):
@@ -27,6 +28,13 @@ class Handle:
             cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=f"cuda:{self.device_index}")
             self._ws[name] = cur
         return cur
+
+    def activate(self, kind: str, owner, load) -> None:
+        """the handle keeps ONE pointer table per model kind; an engine re-points it before use when another
+        engine (a second adapter, another test model) was loaded in between"""
+        if self._active.get(kind) is not owner:
+            load()
+            self._active[kind] = owner
 
     def close(self):
         if self._h:

@@ -27,12 +27,17 @@ class VisionEncoder:
         self.attn_mode = attn_mode
         self.handle = get_handle(self.device)
         self.packed = PackedVit(state, cfg, dtype, self.device)
-        L.check(L.lib.cogs_vit_load(self.handle.h, C.byref(self.packed.struct)), "cogs_vit_load")
+        self._activate()
+
+    def _activate(self):
+        self.handle.activate("vit", self, lambda: L.check(
+            L.lib.cogs_vit_load(self.handle.h, C.byref(self.packed.struct)), "cogs_vit_load"))
 
     def __call__(self, pixel_values: torch.Tensor, grid_sizes: torch.Tensor, merge_sizes: torch.Tensor,
                  attn_mode=None) -> torch.Tensor:
         if not pixel_values.is_cuda:
             raise L.CogsError("pixel_values must live on the GPU")
+        self._activate()
         pixel_values = pixel_values.contiguous()
         gs = [int(v) for v in grid_sizes.reshape(-1).tolist()]
         ms = [int(v) for v in merge_sizes.reshape(-1).tolist()]
@@ -59,9 +64,14 @@ class Projector:
         self.dtype, self.device = dtype, torch.device(device)
         self.handle = get_handle(self.device)
         self.packed = PackedProjector(state, dtype, self.device)
-        L.check(L.lib.cogs_proj_load(self.handle.h, C.byref(self.packed.struct)), "cogs_proj_load")
+        self._activate()
+
+    def _activate(self):
+        self.handle.activate("proj", self, lambda: L.check(
+            L.lib.cogs_proj_load(self.handle.h, C.byref(self.packed.struct)), "cogs_proj_load"))
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        self._activate()
         x = x.contiguous()
         M = x.shape[0]
         es = 2 if self.dtype == torch.bfloat16 else 4

@@ -226,3 +226,74 @@ def random_llm_state(cfg: LlmConfig, seed: int = 2, device="cpu", dtype=torch.fl
         st[p + "mlp.gate_proj.weight"], st[p + "mlp.up_proj.weight"] = r(I, H), r(I, H)
         st[p + "mlp.down_proj.weight"] = r(H, I)
     return st
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LoRA adapters. evaluate/answer_generate.py:181-182 loads two peft adapters
+# ("full_module" for generate, "language_module" for qa_selection; r = 8, alpha = 16 on q,k,v,o,gate,up,down of
+# the 28 decoder layers, the second-stage one also on both projector linears: train/second_stage_training.py:
+# 241-264, first_stage_training.py:447-465) and switches them with set_adapter (:71-73). Here every adapter gets
+# its own MERGED copy of the targeted matrices (W + alpha/r * B.A, summed in fp32, rounded once): 288 GB of HBM
+# hold several 15 GB weight sets, the kernels stay untouched and switching is a pointer-table swap.
+
+LORA_LLM_TARGETS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
+                    "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
+
+
+def _lora_lookup(lora_state: Dict[str, torch.Tensor], module: str):
+    """(A [r,in], B [out,r]) of `module` under any of the key spellings peft writes / the tests use"""
+    for prefix in ("", "base_model.model.model.", "base_model.model.", "model."):
+        for mid in ("", ".default"):
+            a = lora_state.get(f"{prefix}{module}.lora_A{mid}.weight")
+            b = lora_state.get(f"{prefix}{module}.lora_B{mid}.weight")
+            if a is not None and b is not None:
+                return a, b
+    return None
+
+
+def merge_lora(llm_state: Dict[str, torch.Tensor], proj_state: Optional[Dict[str, torch.Tensor]],
+               lora_state: Dict[str, torch.Tensor], cfg: LlmConfig, lora_alpha: float = 16.0):
+    """-> (llm_state', proj_state') with W' = W + (alpha / r) * B @ A for every targeted module; untouched
+    tensors are shared with the inputs (no copy)."""
+    def merged(w, ab):
+        a, b = ab
+        r = a.shape[0]
+        d = (b.to(w.device, torch.float32) @ a.to(w.device, torch.float32)) * (lora_alpha / r)
+        return (w.float() + d).to(w.dtype)
+
+    out = dict(llm_state)
+    for i in range(cfg.num_hidden_layers):
+        for t in LORA_LLM_TARGETS:
+            ab = _lora_lookup(lora_state, f"layers.{i}.{t}")
+            if ab is not None:
+                out[f"layers.{i}.{t}.weight"] = merged(llm_state[f"layers.{i}.{t}.weight"], ab)
+    pout = None
+    if proj_state is not None:
+        pout = dict(proj_state)
+        for t in ("readout.0", "readout.2"):
+            ab = _lora_lookup(lora_state, f"mm_projector.{t}")
+            if ab is not None:
+                pout[t + ".weight"] = merged(proj_state[t + ".weight"], ab)
+    return out, pout
+
+
+def random_lora_state(cfg: LlmConfig, seed: int = 7, r: int = 8, proj_dims=None, device="cpu", dtype=torch.float32,
+                      std: float = 0.05):
+    """test adapter in peft's key layout (both A and B random, so the branch is not a no-op)"""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rnd = lambda *s: (torch.randn(*s, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+    H, I, hd = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+    kvd = cfg.num_key_value_heads * hd
+    dims = {"self_attn.q_proj": (H, H), "self_attn.k_proj": (kvd, H), "self_attn.v_proj": (kvd, H),
+            "self_attn.o_proj": (H, H), "mlp.gate_proj": (I, H), "mlp.up_proj": (I, H), "mlp.down_proj": (H, I)}
+    st = {}
+    for i in range(cfg.num_hidden_layers):
+        for t, (o, n) in dims.items():
+            k = f"base_model.model.model.layers.{i}.{t}"
+            st[k + ".lora_A.weight"], st[k + ".lora_B.weight"] = rnd(r, n), rnd(o, r)
+    if proj_dims is not None:
+        din, dout = proj_dims
+        for t, (o, n) in (("readout.0", (dout, din)), ("readout.2", (dout, dout))):
+            k = f"base_model.model.model.mm_projector.{t}"
+            st[k + ".lora_A.weight"], st[k + ".lora_B.weight"] = rnd(r, n), rnd(o, r)
+    return st

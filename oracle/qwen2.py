@@ -31,10 +31,23 @@ def rotate_half(x):
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
 
 
+def lora_linear(x, w, name: str, lora: Optional[Dict[str, torch.Tensor]], scaling: float):
+    """nn.Linear `name` of the state dict w, plus -- if the adapter targets it -- the UNMERGED low-rank branch of
+    peft==0.15.2 (environment.yml:335) `lora.Linear.forward` in eval mode: result + lora_B(lora_A(x)) * scaling,
+    scaling = lora_alpha / r (second_stage_training.py:257-264: r = 8, alpha = 16). peft is not installed in the
+    build container, so this branch is restated from its published algorithm and is unpinned."""
+    y = F.linear(x, w[name + ".weight"], w.get(name + ".bias"))
+    if lora is not None and (name + ".lora_A.weight") in lora:
+        y = y + F.linear(F.linear(x, lora[name + ".lora_A.weight"]), lora[name + ".lora_B.weight"]) * scaling
+    return y
+
+
 def forward(w: Dict[str, torch.Tensor], embeds: torch.Tensor, *, heads: int, kv_heads: int, layers: int,
             eps: float = 1e-6, theta: float = 1e6, past: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None,
+            lora: Optional[Dict[str, torch.Tensor]] = None, lora_scaling: float = 2.0,
             ) -> Tuple[torch.Tensor, List[Tuple[torch.Tensor, torch.Tensor]]]:
     """Qwen2Model.forward on embeddings [S, H] -> (last_hidden_state [S, H] after final norm, kv)"""
+    lin = lambda t, name: lora_linear(t, w, name, lora, lora_scaling)
     S, H = embeds.shape
     hd = H // heads
     dt = embeds.dtype
@@ -46,9 +59,9 @@ def forward(w: Dict[str, torch.Tensor], embeds: torch.Tensor, *, heads: int, kv_
     for i in range(layers):
         p = f"layers.{i}."
         h = rms_norm(x, w[p + "input_layernorm.weight"], eps)
-        q = F.linear(h, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"]).view(S, heads, hd).transpose(0, 1)
-        k = F.linear(h, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"]).view(S, kv_heads, hd).transpose(0, 1)
-        v = F.linear(h, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"]).view(S, kv_heads, hd).transpose(0, 1)
+        q = lin(h, p + "self_attn.q_proj").view(S, heads, hd).transpose(0, 1)
+        k = lin(h, p + "self_attn.k_proj").view(S, kv_heads, hd).transpose(0, 1)
+        v = lin(h, p + "self_attn.v_proj").view(S, kv_heads, hd).transpose(0, 1)
         q = q * cos + rotate_half(q) * sin
         k = k * cos + rotate_half(k) * sin
         if past:
@@ -64,11 +77,11 @@ def forward(w: Dict[str, torch.Tensor], embeds: torch.Tensor, *, heads: int, kv_
         a = a.masked_fill(~causal, float("-inf"))
         a = F.softmax(a, dim=-1, dtype=torch.float32).to(dt)
         o = torch.matmul(a, vv).transpose(0, 1).reshape(S, H)
-        x = x + F.linear(o, w[p + "self_attn.o_proj.weight"])
+        x = x + lin(o, p + "self_attn.o_proj")
         h = rms_norm(x, w[p + "post_attention_layernorm.weight"], eps)
-        g = F.linear(h, w[p + "mlp.gate_proj.weight"])
-        u = F.linear(h, w[p + "mlp.up_proj.weight"])
-        x = x + F.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
+        g = lin(h, p + "mlp.gate_proj")
+        u = lin(h, p + "mlp.up_proj")
+        x = x + lin(F.silu(g) * u, p + "mlp.down_proj")
     return rms_norm(x, w["norm.weight"], eps), new_kv
 
 

@@ -137,3 +137,65 @@ def test_processor_gpu_path_equals_host_path(dev):
     assert gpu["pixel_values"].is_cuda and gpu["pixel_values"].dtype == torch.bfloat16
     assert torch.equal(gpu["pixel_values"].cpu(), host["pixel_values"].bfloat16())
     assert torch.equal(gpu["grid_sizes"], host["grid_sizes"]) and torch.equal(gpu["input_ids"], host["input_ids"])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
+def test_llm_lora_adapters_vs_unmerged_oracle(dev, dtype, tol):
+    """two adapters = two merged weight sets on one handle; each must match the oracle's UNMERGED peft branch
+    (result + lora_B(lora_A(x)) * alpha/r), and switching back and forth must not mix them up"""
+    from oracle import qwen2 as oq
+    from cogstream_amd.llm import Qwen2Engine
+    from cogstream_amd.weights import merge_lora, random_lora_state
+    cfg, st, base = _llm(dev, dtype)
+    kw = dict(heads=cfg.num_attention_heads, kv_heads=cfg.num_key_value_heads, layers=cfg.num_hidden_layers)
+    strip = lambda d: {k.replace("base_model.model.model.", ""): v for k, v in d.items()}
+    loras = [random_lora_state(cfg, seed=s) for s in (21, 22)]
+    engines = [Qwen2Engine(merge_lora(st, None, l, cfg)[0], cfg, dtype=dtype, device=dev) for l in loras]
+    torch.manual_seed(10)
+    emb = torch.randn(70, cfg.hidden_size) * 0.5
+    ref_base = oq.forward(st, emb, **kw)[0]
+    refs = [oq.forward(st, emb, lora=strip(l), lora_scaling=16.0 / 8, **kw)[0] for l in loras]
+    assert rel_err(refs[0], ref_base) > 0.05 and rel_err(refs[0], refs[1]) > 0.05   # the adapters do something
+    for order in ((0, 1), (1, 0), (0, 0)):
+        for i in order:
+            got = engines[i].forward(emb.to(dev, dtype), None, want_logits=False, want_hidden=True)["hidden"].float()
+            assert rel_err(got, refs[i]) < tol
+    got = base.forward(emb.to(dev, dtype), None, want_logits=False, want_hidden=True)["hidden"].float()
+    assert rel_err(got, ref_base) < tol
+
+
+def test_cogreasoner_set_adapter_switches_llm_and_projector(dev):
+    """peft surface of evaluate/answer_generate.py:71-73,181-182 on the host mirror"""
+    from oracle import vision as ov
+    from cogstream_amd.chat import CogReasoner
+    from cogstream_amd.llm import Qwen2Engine
+    from cogstream_amd.vision import Projector
+    from cogstream_amd.weights import LlmConfig, random_llm_state, random_lora_state, random_proj_state
+    cfg = LlmConfig(**LLM)
+    st = random_llm_state(cfg, seed=7, std=0.05)
+    pst = random_proj_state(576, cfg.hidden_size, seed=4, std=0.05)
+    _, _, enc = _vit(dev, torch.float32, 0)
+    model = CogReasoner(enc, Projector(pst, dtype=torch.float32, device=dev), Qwen2Engine(st, cfg, dtype=torch.float32, device=dev))
+    lora = random_lora_state(cfg, seed=31, proj_dims=(576, cfg.hidden_size))
+    model.load_adapter(st, pst, lora, "full_module")
+    model.load_adapter(st, pst, random_lora_state(cfg, seed=32), "language_module")     # LLM-only adapter
+    with pytest.raises(ValueError):
+        model.set_adapter("nope")
+    torch.manual_seed(11)
+    x = torch.randn(24, 576)
+    s = 16.0 / 8
+    a0, b0 = lora["base_model.model.model.mm_projector.readout.0.lora_A.weight"], lora["base_model.model.model.mm_projector.readout.0.lora_B.weight"]
+    a2, b2 = lora["base_model.model.model.mm_projector.readout.2.lora_A.weight"], lora["base_model.model.model.mm_projector.readout.2.lora_B.weight"]
+    F = torch.nn.functional
+    h = F.linear(x, pst["readout.0.weight"], pst["readout.0.bias"]) + F.linear(F.linear(x, a0), b0) * s
+    h = F.gelu(h)
+    ref_full = F.linear(h, pst["readout.2.weight"], pst["readout.2.bias"]) + F.linear(F.linear(h, a2), b2) * s
+    ref_base = ov.project(pst, x)
+    model.set_adapter("full_module")
+    assert model.active_adapter == "full_module"
+    assert rel_err(model.mm_projector(x.to(dev)).cpu(), ref_full) < 1e-4
+    model.set_adapter("language_module")                       # no projector LoRA -> base projector
+    assert rel_err(model.mm_projector(x.to(dev)).cpu(), ref_base) < 1e-4
+    assert model.llm is not model._adapters["full_module"][0]
+    model.set_adapter("base")
+    assert rel_err(model.mm_projector(x.to(dev)).cpu(), ref_base) < 1e-4

@@ -131,3 +131,23 @@ def test_preprocessing_matches_reference_processor_bit_exact():
     fr = clips[0][0]
     th, tw = int(g["grid_sizes"][0][1]) * 14, int(g["grid_sizes"][0][2]) * 14
     assert np.array_equal(pr.resize_bicubic_exact(fr, (th, tw)), pr._resize_bicubic(fr, (th, tw)))
+
+
+def test_merge_lora_equals_unmerged_branch_fp32():
+    """weights.merge_lora (what the product loads) against the oracle's unmerged peft branch, on the CPU in fp32"""
+    from oracle import qwen2 as oq
+    from cogstream_amd.weights import LlmConfig, merge_lora, random_llm_state, random_lora_state
+    cfg = LlmConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                    num_key_value_heads=2, vocab_size=96)
+    st = random_llm_state(cfg, seed=3, std=0.08)
+    lora = random_lora_state(cfg, seed=4, std=0.08)
+    kw = dict(heads=4, kv_heads=2, layers=2)
+    torch.manual_seed(0)
+    emb = torch.randn(19, 64)
+    merged, none = merge_lora(st, None, lora, cfg, lora_alpha=16.0)
+    assert none is None and merged["embed_tokens.weight"] is st["embed_tokens.weight"]      # untouched tensors are shared
+    a = oq.forward(merged, emb, **kw)[0]
+    b = oq.forward(st, emb, lora={k.replace("base_model.model.model.", ""): v for k, v in lora.items()},
+                   lora_scaling=2.0, **kw)[0]
+    assert rel_err(a, b) < 1e-5
+    assert rel_err(a, oq.forward(st, emb, **kw)[0]) > 0.05
