@@ -166,9 +166,47 @@ class CogReasoner:
         self.active_adapter = adapter_name
 
     # ------------------------------------------------------------------ vision
-    def encode_images(self, pixel_values, grid_sizes, merge_sizes) -> torch.Tensor:
+    def enable_visual_cache(self, max_videos: int = 64) -> None:
+        """Streaming-session cache: projected visual tokens per video segment, keyed
+        by (content key from the processor, grid t x h x w, merge size, projector in use). The reference re-encodes
+        every segment on every turn (evaluate/answer_generate.py:130-148 rebuilds the whole conversation); frames
+        are independent under block-diagonal attention and the projector is per token, so a cached segment is
+        bit-identical to a recomputed one. A segment whose resize target drifted (the token budget is shared by
+        all frames of the conversation) has a different grid and simply misses."""
+        from collections import OrderedDict
+        self._vcache = OrderedDict()
+        self._vcache_max = max_videos
+        self.visual_cache_stats = {"hits": 0, "misses": 0}
+
+    def encode_images(self, pixel_values, grid_sizes, merge_sizes, video_keys=None) -> torch.Tensor:
         """:264-276"""
-        return self.mm_projector(self.vision_encoder(pixel_values, grid_sizes, merge_sizes))
+        cache = getattr(self, "_vcache", None)
+        if cache is None or video_keys is None or len(video_keys) != int(grid_sizes.shape[0]):
+            return self.mm_projector(self.vision_encoder(pixel_values, grid_sizes, merge_sizes))
+        gs = [tuple(int(x) for x in g) for g in grid_sizes.tolist()]
+        ms = [int(m) for m in merge_sizes.tolist()]
+        rows = [t * h * w for t, h, w in gs]
+        offs = [0]
+        for r in rows:
+            offs.append(offs[-1] + r)
+        keys = [(k, g, m, id(self.mm_projector)) for k, g, m in zip(video_keys, gs, ms)]
+        miss = [v for v, k in enumerate(keys) if k not in cache]
+        self.visual_cache_stats["hits"] += len(keys) - len(miss)
+        self.visual_cache_stats["misses"] += len(miss)
+        if miss:
+            px = pixel_values if len(miss) == len(keys) else torch.cat([pixel_values[offs[v]:offs[v + 1]] for v in miss])
+            tok = self.mm_projector(self.vision_encoder(px, grid_sizes[miss], merge_sizes[miss]))
+            o = 0
+            for v in miss:
+                n = rows[v] // (ms[v] * ms[v])
+                cache[keys[v]] = tok[o:o + n].clone()
+                o += n
+        for k in keys:
+            cache.move_to_end(k)
+        out = torch.cat([cache[k] for k in keys], dim=0) if len(keys) > 1 else cache[keys[0]].clone()
+        while len(cache) > self._vcache_max:   # callers edit the result in place (event compression): always a copy
+            cache.popitem(last=False)
+        return out
 
     def _bf16_round(self, x: torch.Tensor) -> torch.Tensor:
         return x.to(torch.bfloat16).to(torch.float32) if self.dtype == torch.bfloat16 else x
@@ -264,7 +302,7 @@ class CogReasoner:
     # ------------------------------------------------------------------ multimodal assembly
     def prepare_inputs_labels_for_multimodal(self, input_ids=None, attention_mask=None, pixel_values=None,
                                              grid_sizes=None, merge_sizes=None, modals=None, total_image_num=0,
-                                             if_visual=True):
+                                             if_visual=True, video_keys=None):
         """:513-584 -> (inputs_embeds [1,S',H] on the device, attention_mask [1,S'])"""
         B, N = input_ids.shape
         assert B == 1, "Token compression is only supported for batch_size=1"
@@ -274,7 +312,7 @@ class CogReasoner:
         if if_visual:
             pixel_values = pixel_values.to(self.device)
             batched = grid_sizes.prod(dim=1).div(merge_sizes ** 2).long()
-            mm = self.encode_images(pixel_values, grid_sizes, merge_sizes)
+            mm = self.encode_images(pixel_values, grid_sizes, merge_sizes, video_keys=video_keys)
             text_rows = [m == "text" for m in modals]
             if any(text_rows):  # _get_valid_visual_tokens (:336-347)
                 keep = torch.cat([torch.full((int(n),), not tr, dtype=torch.bool) for n, tr in zip(batched, text_rows)])
@@ -350,7 +388,7 @@ class CogReasoner:
 
     @torch.no_grad()
     def generate(self, pixel_values=None, grid_sizes=None, merge_sizes=None, modals=None, new_input_ids=None,
-                 new_attention_mask=None, selection_module_output="", if_visual=True, **kwargs):
+                 new_attention_mask=None, selection_module_output="", if_visual=True, video_keys=None, **kwargs):
         """:753-807 -> (new token ids [1, n], selection_module_output)"""
         for k in ("input_ids", "past_key_values", "attention_mask", "position_ids", "tokenizer", "hist_qs", "hist_as",
                   "current_question", "original_text"):
@@ -362,7 +400,7 @@ class CogReasoner:
             embeds, _ = self.prepare_inputs_labels_for_multimodal(
                 input_ids=new_input_ids, attention_mask=new_attention_mask, pixel_values=pixel_values,
                 grid_sizes=grid_sizes, merge_sizes=merge_sizes, modals=modals, total_image_num=total_image_num,
-                if_visual=if_visual)
+                if_visual=if_visual, video_keys=video_keys)
             embeds = embeds[0]
         else:
             embeds = self.llm.embed_tokens(new_input_ids.reshape(-1))

@@ -314,7 +314,12 @@ class CogStreamProcessor:
         text = expand_image_tokens(text, per_image)
         enc = self.tokenizer(text, return_tensors="pt")
         hist_qs, hist_as, cur_q = process_history_qas(conversation)
+        # content keys of the video segments (xxh64 of the raw frame bytes) for the model's visual-token cache
+        import xxhash
+        video_keys = [xxhash.xxh64((v.cpu().numpy() if isinstance(v, torch.Tensor) else np.ascontiguousarray(v)).tobytes()).hexdigest()
+                      for v in videos]
         out = {
+            "video_keys": video_keys,
             "input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"],
             "modals": ["video"] * len(videos), "tokenizer": self.tokenizer,
             "hist_qs": hist_qs, "hist_as": hist_as, "current_question": cur_q,

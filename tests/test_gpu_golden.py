@@ -168,3 +168,27 @@ def test_multi_turn_session_runs(dev):
     assert recs[0]["predicted_coi"] == [] and len(recs[3]["predicted_coi"]) == 3
     assert all(isinstance(r["prediction"], str) for r in recs)
     assert shard_videos(10, 1, 4) == [1, 5, 9] and shard_videos(10, 3, 4) == [3, 7, 1]
+
+
+def test_visual_token_cache_is_transparent(dev):
+    """section 8f rank 3: the same streaming session with the visual-token cache on (and GPU pre-processing) must
+    produce the same records as without; later turns hit the cache for the segments already seen"""
+    from cogstream_amd import processing as pr
+    from cogstream_amd.answer_generate import run_session
+    from toy_tokenizer import ToyTokenizer
+    tok = ToyTokenizer()
+    segs = []
+    for i in range(3):
+        fr, ts = pr.synthetic_clip(4, 56, 56, kind="drift", clip_idx=i)
+        segs.append({"video": fr, "timestamps": [t + 4 * i for t in ts], "questions": [f"What happens in part {i}?"]})
+    recs = []
+    for cached in (False, True):
+        model = _tiny_model(dev, torch.bfloat16, 0)
+        if cached:
+            model.enable_visual_cache()
+        random.seed(3)
+        torch.manual_seed(3)
+        recs.append(run_session(model, pr.CogStreamProcessor(tok, device=dev), segs, max_new_tokens=4, do_sample=False))
+    assert [r["prediction"] for r in recs[0]] == [r["prediction"] for r in recs[1]]
+    assert [r["predicted_coi"] for r in recs[0]] == [r["predicted_coi"] for r in recs[1]]
+    assert model.visual_cache_stats == {"hits": 3, "misses": 3}      # turn t sees t+1 segments: 1+2+3 = 6 lookups
