@@ -144,6 +144,7 @@ SIGNATURES = {
     "cogs_project": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t]),
     "cogs_llm_load": (c_int, [c_void_p, C.POINTER(LlmWeights)]),
     "cogs_llm_workspace_bytes": (c_int, [c_void_p, c_int, c_int, C.POINTER(c_size_t)]),
+    "cogs_llm_forward_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t]),
     "cogs_llm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, C.POINTER(KV), c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t]),
 }

@@ -231,20 +231,25 @@ class CogReasoner:
         assign_h = assign.cpu().tolist()
         ts = timestamps.cpu() if isinstance(timestamps, torch.Tensor) else torch.tensor(timestamps)
         image_id = self.config.image_token_index
-        pooled = []
+        # the K event prompts and the question are K+1 independent sequences: the reference runs one forward per
+        # sequence (:303-322), here they are ONE var-len prefill with per-sequence mean pooling
+        segs = []
         for k in range(K):
             frames = [i for i in range(T) if assign_h[i] == k]
             prompt = create_visual_summary_prompt(len(frames) * P, [ts[i] for i in frames])
             ids = self.tokenizer(prompt, return_tensors="pt")["input_ids"].reshape(-1).to(torch.int64)
-            rows = torch.tensor([f * P + p for f in frames for p in range(P)], dtype=torch.int64)
+            rows = (torch.tensor(frames, dtype=torch.int64)[:, None] * P + torch.arange(P, dtype=torch.int64)[None, :]).reshape(-1)
             sel = ids == image_id
             assert int(sel.sum()) == rows.numel()
             idx = ids.clone()
             idx[sel] = -(rows + 1)
-            pooled.append(self._pooled_forward(idx, mm_features))
+            segs.append(idx)
         q = self.tokenizer(self.current_question, padding=True, truncation=True, return_tensors="pt", max_length=128)
-        qvec = self._pooled_forward(q["input_ids"].reshape(-1).to(torch.int64), None)
-        cos = self._bf16_round(ops.cosine(qvec, torch.stack(pooled).contiguous())).cpu()
+        segs.append(q["input_ids"].reshape(-1).to(torch.int64))
+        emb = ops.gather_rows(self.llm.packed.embed, mm_features, torch.cat(segs).to(self.device))
+        pooled_all = self._bf16_round(self.llm.forward_segments(emb, [int(x.numel()) for x in segs]))  # mean of bf16 is bf16
+        qvec, pooled = pooled_all[K], pooled_all[:K]
+        cos = self._bf16_round(ops.cosine(qvec.contiguous(), pooled.contiguous())).cpu()
         assert cos.shape[0] == K
         self.last_debug.update(cosine_raw=cos.clone())
         if self.cosine_override is not None:  # test hook: pin the branch below with forced similarities

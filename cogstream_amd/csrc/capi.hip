@@ -486,7 +486,8 @@ static int llm_nsplit(int ctx) {
 }
 
 static size_t llm_carve(const cogs_llm_weights& w, int S, int max_ctx, Carver& c, void** x, void** ln, void** qkv,
-                        void** att, void** act, float** rc, float** rs, void** split, size_t* split_bytes) {
+                        void** att, void** act, float** rc, float** rs, void** split, size_t* split_bytes,
+                        int32_t** pos = nullptr, int32_t** cu = nullptr) {
     const size_t es = esize(w.dtype);
     const int qd = (w.heads + 2 * w.kv_heads) * w.head_dim;
     *x = c.take((size_t)S * w.hidden * es);
@@ -498,6 +499,10 @@ static size_t llm_carve(const cogs_llm_weights& w, int S, int max_ctx, Carver& c
     *rs = nullptr;
     *split_bytes = (size_t)llm_nsplit(max_ctx) * w.heads * (w.head_dim + 2) * sizeof(float);
     *split = c.take(*split_bytes);
+    int32_t* pp = (int32_t*)c.take((size_t)S * sizeof(int32_t));          // per-row positions (segmented forward)
+    int32_t* cc = (int32_t*)c.take(((size_t)S + 1) * sizeof(int32_t));    // cu_seqlens (at most S segments)
+    if (pos) *pos = pp;
+    if (cu) *cu = cc;
     return c.off;
 }
 
@@ -509,8 +514,11 @@ cogs_status cogs_llm_workspace_bytes(cogs_handle h, int max_tokens, int max_cont
     return COGS_OK;
 }
 
-cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embeds, int S, cogs_kv* kv,
-                             float* last_logits, float* pooled_mean, void* hidden_out, void* ws, size_t ws_bytes) {
+// one implementation behind cogs_llm_forward and cogs_llm_forward_segments: nseg > 0 = stateless forward over
+// nseg independent sequences stored back to back (causal attention and positions restart at every cu_host[s])
+static cogs_status llm_forward_impl(cogs_handle h, cogs_stream stream, const void* embeds, int S, cogs_kv* kv,
+                                    float* last_logits, float* pooled_mean, void* hidden_out, void* ws, size_t ws_bytes,
+                                    const int32_t* cu_host, int nseg, float* pooled_seg) {
     if (!h || !h->llm_ok || !embeds || S <= 0) return COGS_E_INVALID;
     const cogs_llm_weights& w = h->llm;
     hipStream_t st = (hipStream_t)stream;
@@ -522,11 +530,29 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
     if (kv && (!kv->k || !kv->v || ctx > kv->max_len)) return COGS_E_INVALID;
     Carver c(ws, ws_bytes);
     void *x, *ln, *qkv, *att, *act, *split; float *rc, *rs; size_t split_bytes;
-    const size_t need = llm_carve(w, S, ctx, c, &x, &ln, &qkv, &att, &act, &rc, &rs, &split, &split_bytes);
+    int32_t *pos_d = nullptr, *cu_d = nullptr;
+    const size_t need = llm_carve(w, S, ctx, c, &x, &ln, &qkv, &att, &act, &rc, &rs, &split, &split_bytes, &pos_d, &cu_d);
     if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
+    int max_seg = 0;
+    if (nseg > 0) {
+        if (kv || !cu_host || cu_host[0] != 0 || cu_host[nseg] != S || nseg > S) return COGS_E_INVALID;
+        h->h_cu.assign(cu_host, cu_host + nseg + 1);
+        h->h_lo.resize(S);
+        for (int sgm = 0; sgm < nseg; ++sgm) {
+            const int b = cu_host[sgm], e = cu_host[sgm + 1];
+            if (e <= b) return COGS_E_INVALID;
+            max_seg = e - b > max_seg ? e - b : max_seg;
+            for (int i = b; i < e; ++i) h->h_lo[i] = i - b;
+        }
+        // the staging vectors live in the handle; the stream is synchronised before they can change again
+        if (hipStreamSynchronize(st) != hipSuccess) return COGS_E_HIP;
+        if (hipMemcpyAsync(cu_d, h->h_cu.data(), (nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(pos_d, h->h_lo.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess)
+            return COGS_E_HIP;
+    }
 
     if (hipMemcpyAsync(x, embeds, (size_t)S * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return COGS_E_HIP;
-    { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_llm_rope_table(st, rc, rs, nullptr, pos0, S, h->llm_inv_freq, hd / 2)); }
+    { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_llm_rope_table(st, rc, rs, nseg > 0 ? pos_d : nullptr, pos0, S, h->llm_inv_freq, hd / 2)); }
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < w.layers; ++l) {
         const cogs_llm_layer& L = h->llm_layers[l];
@@ -564,6 +590,7 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
             a.ldq = qd; a.ldk = ldkv; a.ldv = ldkv; a.ldo = qd_q;
             a.q_len = S; a.kv_len = ctx; a.hq = w.heads; a.hkv = w.kv_heads; a.head_dim = hd; a.scale = scale;
             a.causal = 1; a.q_pos0 = pos0;
+            if (nseg > 0) { a.cu_seqlens = cu_d; a.nseg = nseg; a.max_seqlen = max_seg; }
             if (S == 1 && dt == COGS_DT_BF16 && hd == 128) {
                 a.nsplit = llm_nsplit(ctx); a.ws = split; a.ws_bytes = split_bytes;
             }
@@ -591,6 +618,16 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
         }
     }
     if (kv) kv->len = ctx;
+    if (nseg > 0) {   // final norm over every row, then one mean per sequence
+        if (!pooled_seg) return COGS_E_INVALID;
+        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, w.final_norm, S, H, w.rms_eps)); }
+        for (int sgm = 0; sgm < nseg; ++sgm) {
+            PROF(COGS_PROF_OTHER);
+            COGS_TRY(cogs_k_mean_rows(st, dt, (const char*)ln + (size_t)cu_host[sgm] * H * es, H,
+                                      cu_host[sgm + 1] - cu_host[sgm], H, pooled_seg + (size_t)sgm * H));
+        }
+        return COGS_OK;
+    }
     const bool need_all = pooled_mean || hidden_out;
     if (need_all) {
         void* hn = hidden_out ? hidden_out : ln;
@@ -610,6 +647,19 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
         { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
     }
     return COGS_OK;
+}
+
+cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embeds, int S, cogs_kv* kv,
+                             float* last_logits, float* pooled_mean, void* hidden_out, void* ws, size_t ws_bytes) {
+    return llm_forward_impl(h, stream, embeds, S, kv, last_logits, pooled_mean, hidden_out, ws, ws_bytes, nullptr, 0, nullptr);
+}
+
+cogs_status cogs_llm_forward_segments(cogs_handle h, cogs_stream stream, const void* embeds, int S,
+                                      const int32_t* cu_seqlens_host, int nseg, float* pooled_means, void* ws,
+                                      size_t ws_bytes) {
+    if (nseg <= 0 || !cu_seqlens_host || !pooled_means) return COGS_E_INVALID;
+    return llm_forward_impl(h, stream, embeds, S, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, cu_seqlens_host, nseg,
+                            pooled_means);
 }
 
 }  // extern "C"

@@ -71,6 +71,25 @@ class Qwen2Engine:
             out["hidden"] = hidden
         return out
 
+    def forward_segments(self, embeds: torch.Tensor, seg_lens: Sequence[int]) -> torch.Tensor:
+        """several independent sequences stored back to back -> mean of the final hidden states of each, fp32
+        [nseg, H] (cogs_llm_forward_segments): one var-len prefill instead of one forward per sequence"""
+        self._activate()
+        embeds = embeds.contiguous()
+        S = embeds.shape[0]
+        cu = [0]
+        for n in seg_lens:
+            cu.append(cu[-1] + int(n))
+        assert cu[-1] == S and all(int(n) > 0 for n in seg_lens)
+        nbytes = C.c_size_t()
+        L.check(L.lib.cogs_llm_workspace_bytes(self.handle.h, S, S, C.byref(nbytes)), "cogs_llm_workspace_bytes")
+        ws = self.handle.workspace("llm", nbytes.value)
+        out = torch.empty(len(seg_lens), self.cfg.hidden_size, device=self.device, dtype=torch.float32)
+        cua = (C.c_int32 * len(cu))(*cu)
+        L.check(L.lib.cogs_llm_forward_segments(self.handle.h, L.current_stream(), embeds.data_ptr(), S, cua, len(seg_lens),
+                                                out.data_ptr(), ws.data_ptr(), ws.numel()), "cogs_llm_forward_segments")
+        return out
+
     def generate(self, embeds: torch.Tensor, *, max_new_tokens: int, eos_token_id: Sequence[int] = (),
                  do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
                  repetition_penalty: float = 1.0, allowed_ids: Optional[Sequence[int]] = None,

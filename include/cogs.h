@@ -254,6 +254,16 @@ cogs_status cogs_llm_forward(cogs_handle h, cogs_stream stream, const void* embe
                              float* last_logits, float* pooled_mean, void* hidden_out, void* ws,
                              size_t ws_bytes);
 
+/* nseg independent sequences stored back to back in embeds [S,H] (cu_seqlens_host [nseg+1], host memory, 0 .. S):
+ * one stateless forward -- positions and causal attention restart at every sequence -- and the mean over each
+ * sequence of the final hidden states -> pooled_means [nseg, H] fp32. Replaces the K sequential
+ * self.get_model()(inputs_embeds=...).last_hidden_state.mean(dim=1) calls of select_events_based_on_summary
+ * (model/cogreasoner_chat.py:303-322: one per event, one for the question). Synchronises the stream once (host
+ * staging of the position table). Workspace: cogs_llm_workspace_bytes(h, S, S). */
+cogs_status cogs_llm_forward_segments(cogs_handle h, cogs_stream stream, const void* embeds, int S,
+                                      const int32_t* cu_seqlens_host, int nseg, float* pooled_means, void* ws,
+                                      size_t ws_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,3 +199,25 @@ def test_cogreasoner_set_adapter_switches_llm_and_projector(dev):
     assert model.llm is not model._adapters["full_module"][0]
     model.set_adapter("base")
     assert rel_err(model.mm_projector(x.to(dev)).cpu(), ref_base) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_llm_forward_segments_equals_separate_passes(dev, dtype, tol):
+    """cogs_llm_forward_segments (one var-len prefill, per-sequence positions / causal attention / mean pooling)
+    against one stateless forward per sequence -- the reference's K event-summary passes + the question pass"""
+    from oracle import qwen2 as oq
+    cfg, st, eng = _llm(dev, dtype)
+    kw = dict(heads=cfg.num_attention_heads, kv_heads=cfg.num_key_value_heads, layers=cfg.num_hidden_layers)
+    torch.manual_seed(12)
+    lens = [150, 1, 37, 260, 9]                       # ragged, incl. a single token and > 2 attention q-blocks
+    emb = torch.randn(sum(lens), cfg.hidden_size) * 0.5
+    got = eng.forward_segments(emb.to(dev, dtype), lens)
+    assert got.shape == (len(lens), cfg.hidden_size) and got.dtype == torch.float32
+    o = 0
+    for i, n in enumerate(lens):
+        seg = emb[o:o + n]
+        one = eng.forward(seg.to(dev, dtype), None, want_logits=False, want_pooled=True)["pooled"]
+        assert rel_err(got[i], one) < tol
+        if dtype == torch.float32:
+            assert rel_err(got[i].cpu(), oq.forward(st, seg, **kw)[0].mean(0)) < 1e-4
+        o += n
