@@ -221,3 +221,56 @@ def test_llm_forward_segments_equals_separate_passes(dev, dtype, tol):
         if dtype == torch.float32:
             assert rel_err(got[i].cpu(), oq.forward(st, seg, **kw)[0].mean(0)) < 1e-4
         o += n
+
+
+def test_full_size_encoder_is_frame_separable(dev):
+    """BASELINE.json cfg2 at real dimensions (64 x 480p frames, ViT 1152 x 27, projector 3584): encoding frame
+    shards separately and concatenating must be BIT-identical to encoding the clip at once -- the property the
+    multi-GPU frame sharding rests on -- and GPU pre-processing must be deterministic"""
+    from cogstream_amd import processing as pr
+    from cogstream_amd.preprocess_gpu import preprocess_videos_gpu
+    from cogstream_amd.vision import Projector, VisionEncoder
+    from cogstream_amd.weights import VisionConfig, random_proj_state, random_vit_state
+    cfg = VisionConfig()
+    enc = VisionEncoder(random_vit_state(cfg, 0, dev, torch.bfloat16), cfg, dtype=torch.bfloat16, device=dev)
+    proj = Projector(random_proj_state(cfg.hidden_size, 3584, 1, dev, torch.bfloat16), dtype=torch.bfloat16, device=dev)
+    frames, _ = pr.synthetic_clip(64, kind="drift")
+    d = torch.from_numpy(frames).to(dev)
+    f1, f2 = preprocess_videos_gpu([d]), preprocess_videos_gpu([d])
+    assert torch.equal(f1["pixel_values"], f2["pixel_values"]) and f1["grid_sizes"].tolist() == [[64, 22, 42]]
+    pix, merge = f1["pixel_values"], torch.tensor([2])
+    full = proj(enc(pix, f1["grid_sizes"], merge))
+    assert full.shape == (64 * 231, 3584) and bool(torch.isfinite(full.float()).all())
+    per = 22 * 42
+    parts = []
+    for b, e in ((0, 24), (24, 25), (25, 64)):                       # ragged shards, incl. a single frame
+        parts.append(proj(enc(pix[b * per:e * per], torch.tensor([[e - b, 22, 42]]), merge)))
+    assert torch.equal(torch.cat(parts), full)
+
+
+def test_full_size_llm_decode_as_accurate_as_prefill(dev):
+    """Qwen2-7B dimensions, random weights: prefill(S) + one cached decode step against prefill(S+1) -- the GEMV
+    path with the fused KV-row write, split-KV decode attention and the fused RMSNorm at full size. Over 28 random
+    layers bf16 rounding alone moves the logits by ~5 % of their range, so the yardstick is the fp32 parity engine
+    on the same weights: the decode path must be as close to it as the prefill path is."""
+    from cogstream_amd.llm import Qwen2Engine
+    from cogstream_amd.weights import LlmConfig, random_llm_state
+    cfg = LlmConfig()
+    st = random_llm_state(cfg, 2, dev, torch.bfloat16)
+    eng = Qwen2Engine(st, cfg, dtype=torch.bfloat16, device=dev)
+    torch.manual_seed(3)
+    S = 1500
+    emb = (torch.randn(S + 1, cfg.hidden_size, device=dev) * 0.02).to(torch.bfloat16)
+    ref = eng.forward(emb, None)["logits"]
+    cache = eng.new_cache(S + 8)
+    eng.forward(emb[:S], cache, want_logits=False)
+    got = eng.forward(emb[S:], cache)["logits"]
+    assert cache.len == S + 1
+    eng32 = Qwen2Engine({k: v.float() for k, v in st.items()}, cfg, dtype=torch.float32, device=dev)
+    truth = eng32.forward(emb.float(), None)["logits"]
+    rms = lambda a: float((a - truth).pow(2).mean().sqrt())
+    assert rms(ref) < 0.03 * float(truth.abs().max())              # bf16 prefill within bf16 noise of fp32
+    assert rms(got) < 1.25 * rms(ref) + 1e-3                       # the decode path is no worse
+    assert rel_err(got, ref) < 6e-2
+    del eng, eng32, cache
+    torch.cuda.empty_cache()
