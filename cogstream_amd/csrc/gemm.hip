@@ -692,11 +692,42 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     const int n_pad = (g.N + BN3 - 1) / BN3 * BN3;
     static const int env_waste = getenv("COGS_GEMM_PPWASTE") ? atoi(getenv("COGS_GEMM_PPWASTE")) : 112;
     const bool pp_fits = n_pad * 100 <= g.N * env_waste;   // default: <= 12 % of the MFMAs spent on N padding (N = 1152 -> 1280 measured faster than the 256x128 ring kernel)
-    if (!env_nopp && !env_small && g.dtype == COGS_DT_BF16 && g.M >= 1024 && pp_fits && !g.force_small_tile) {
+    if (!env_nopp && !env_small && g.dtype == COGS_DT_BF16 && g.M >= 1024 && pp_fits && !g.force_small_tile &&
+        !g.force_mid_tile) {
         p.nbm = (g.M + BM3 - 1) / BM3;
         p.nbn = (g.N + BN3 - 1) / BN3;
         static const bool env_nostore = getenv("COGS_GEMM_NOSTORE") != nullptr;
-        dispatch_pp(st, p, p.nbm * p.nbn, env_nostore ? EPI_NOSTORE : cogs_epi_mask(g));
+        // Round-aligned split. The persistent kernel walks nbm*nbn tiles with 256 workgroups; when the last round
+        // is mostly empty (N = 1152 at cfg2: 1155 tiles = 4.5 rounds, half the CUs idle for a whole tile time) the
+        // leading row blocks that make up WHOLE rounds stay here and the remaining rows go to the 256x128 kernel,
+        // whose half-size tiles fill the chip again (rows are independent: same arithmetic per row).
+        static const bool env_nosplit = getenv("COGS_GEMM_NOSPLIT") != nullptr;
+        const int nb = p.nbm * p.nbn;
+        const int rounds = nb / PERSISTENT_WGS, rem = nb % PERSISTENT_WGS;
+        // (pays when a tile is long against a second launch: K >= 2048; measured at K = 1152: -2 %, K = 3584: +5 %,
+        // K = 4352: +2 %, K = 18944: +8 %)
+        if (!env_nosplit && !env_nostore && g.K >= 2048 && rounds >= 2 && rem > 0 && rem * 10 < PERSISTENT_WGS * 7) {
+            const int mb_main = rounds * PERSISTENT_WGS / p.nbn;          // whole row blocks within the full rounds
+            const int rows_main = mb_main * BM3, rows_rem = g.M - rows_main;
+            if (mb_main > 0 && rows_rem >= 512) {
+                CogsGemm b = g;
+                b.M = rows_rem; b.force_mid_tile = 1;
+                b.A = (const char*)g.A + (size_t)rows_main * g.lda * es;
+                b.C = (char*)g.C + (size_t)rows_main * g.ldc * (g.out_f32 ? 4 : es);
+                if (g.residual) b.residual = (const char*)g.residual + (size_t)rows_main * g.ldr * es;
+                if (g.rope_cos) {
+                    const size_t per_row = (size_t)(g.head_dim / 2) * (g.rope_sin ? 1 : 2);
+                    b.rope_cos = g.rope_cos + (size_t)rows_main * per_row;
+                    if (g.rope_sin) b.rope_sin = g.rope_sin + (size_t)rows_main * per_row;
+                }
+                p.M = rows_main; p.nbm = mb_main;
+                dispatch_pp(st, p, p.nbm * p.nbn, cogs_epi_mask(g));
+                const int rc2 = COGS_LAUNCH_CHECK();
+                if (rc2 != COGS_OK) return rc2;
+                return cogs_k_gemm(st, b);
+            }
+        }
+        dispatch_pp(st, p, nb, env_nostore ? EPI_NOSTORE : cogs_epi_mask(g));
         return COGS_LAUNCH_CHECK();
     }
     const bool big = g.M >= 512 && !g.force_small_tile && !env_small;

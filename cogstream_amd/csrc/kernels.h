@@ -25,6 +25,7 @@ struct CogsGemm {
     int rope_cols = 0;
     int head_dim = 0;
     int force_small_tile = 0;                // testing: always use the 128x128 kernel
+    int force_mid_tile = 0;                  // internal: skip the ping-pong kernel (remainder rows of a round-aligned split)
     const void* rms_gamma = nullptr;         // M == 1 only: RMS-normalise A on the fly with this weight
     float rms_eps = 0.f;
     // M == 1 only: output columns [kv_col0, kv_col0 + kv_dim) go to kv_k[0..kv_dim), the next kv_dim to kv_v
