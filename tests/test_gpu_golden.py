@@ -192,3 +192,41 @@ def test_visual_token_cache_is_transparent(dev):
     assert [r["prediction"] for r in recs[0]] == [r["prediction"] for r in recs[1]]
     assert [r["predicted_coi"] for r in recs[0]] == [r["predicted_coi"] for r in recs[1]]
     assert model.visual_cache_stats == {"hits": 3, "misses": 3}      # turn t sees t+1 segments: 1+2+3 = 6 lookups
+
+
+def test_full_size_kmeans_and_mask_match_oracle(dev):
+    """BASELINE.json configs[2] scale (256 frames, features [256, 50 x 3584] bf16, K = 18; pixel values of 64
+    frames at 308x588): cluster assignments, near-centroid frame picks and the pixel-difference keep-mask of the
+    HIP path are BIT-equal to the oracle's on the same inputs"""
+    from oracle import compress as oc
+    from oracle import kmeans as ok
+    from cogstream_amd import ops
+    from cogstream_amd.kmeans import kmeans_with_time_min_max, select_additional_frames
+    T, P, D, K = 256, 50, 3584, 18
+    g = torch.Generator().manual_seed(11)
+    centres = torch.randn(K, 1, D, generator=g)
+    which = torch.arange(T) * K // T
+    feats = (centres[which] + 0.35 * torch.randn(T, P, D, generator=g)).to(torch.bfloat16)     # clustered synthetic data
+    ts = torch.arange(T, dtype=torch.float32)
+    random.seed(0)
+    torch.manual_seed(0)
+    cf, ct, assign = kmeans_with_time_min_max(feats.to(dev), ts, K)
+    picks = select_additional_frames(feats.to(dev), cf, assign, 2)
+    random.seed(0)
+    torch.manual_seed(0)
+    ocf, oct_, oassign = ok.kmeans_with_time_min_max(feats, ts, K)
+    opicks = ok.select_additional_frames(feats, ocf, oassign, 2)
+    assert torch.equal(assign.cpu(), oassign)
+    assert sorted(torch.cat(picks).cpu().tolist()) == sorted(torch.cat(opicks).tolist())
+    # pixel-difference mask at cfg2 size
+    Tp, gh, gw = 64, 22, 42
+    pix = (torch.randn(Tp * gh * gw, 588, generator=g) * 0.4)
+    pix[gh * gw:] = pix[:-gh * gw] * 0.5 + pix[gh * gw:] * 0.5                               # correlate neighbouring frames
+    pix = pix.to(torch.bfloat16)
+    grid, merge = torch.tensor([[Tp, gh, gw]]), torch.tensor([2])
+    minor = list(range(0, Tp, 7))
+    md = torch.zeros(Tp, dtype=torch.uint8, device=dev)
+    md[minor] = 1
+    mask = ops.pixdiff_mask(pix.to(dev), Tp, gh * gw // 4, 0.1, 1, md)
+    om = oc.compression_mask(pix, grid, merge, ["video"], minor_frame_indices=minor)
+    assert torch.equal(om, mask.cpu().bool()) and 0 < int(mask.sum()) < mask.numel()
