@@ -7,8 +7,9 @@ Restates (not imports) the reference's host preprocessing:
   chat template / <image>    model/chat_template.json, model/processing_cogreasoner.py:707-730,752-801
   history extraction         model/processing_cogreasoner.py:936-956
 Video DECODING (ffmpeg/decord, processing_cogreasoner.py:326-429) is out of scope: clips arrive as
-uint8 arrays + timestamps. This module is numpy/PIL/str only; nothing here
-touches the GPU, and nothing here imports the oracle."""
+uint8 arrays + timestamps. The functions are numpy/PIL/str only; the one GPU hook is
+CogStreamProcessor(device=...), which hands the frames to preprocess_gpu.py (same values, bit for bit) instead of
+PIL. Nothing here imports the oracle."""
 from __future__ import annotations
 
 import math
