@@ -61,6 +61,7 @@ class AttnDesc(C.Structure):
         ("causal", c_int), ("q_pos0", c_int),
         ("force_rowwise", c_int),
         ("nsplit", c_int), ("ws", c_void_p), ("ws_bytes", c_size_t),
+        ("q_prescaled", c_int),
     ]
 
 

@@ -40,6 +40,7 @@ struct AttnArgs {
     int causal;
     int nsplit;                     // >1: keys split over blocks, partials go to part_o/part_ml
     int gqa_pack;                   // decode: the q-heads of one kv head are the 16 query columns
+    int q_prescaled;                // Q already carries scale*log2(e): use the PRE kernels
     float* part_o;                  // [nsplit][q_len][hq][HD] unnormalised
     float* part_ml;                 // [nsplit][q_len][hq][2]  (running max (log2 domain), sum)
 };
@@ -62,8 +63,13 @@ __device__ __forceinline__ int k_swz(int row) { return (row & 3) | (((row >> 3) 
 // NQ = 16-row query sub-tiles per wave: 2 -> 4 waves x 32 rows (256 threads, 2 waves per SIMD at 2 workgroups per CU);
 // 1 -> 8 waves x 16 rows (512 threads): half the accumulator / score registers per wave, so twice the waves per
 // SIMD overlap each other's MFMA, VALU and LDS phases, at the price of reading every K/V fragment for 16 rows only.
-template <int HD, int NQ>
-__global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : 2) void attn_fwd_bf16_kernel(AttnArgs p) {
+// PRE = Q arrives pre-multiplied by scale*log2(e) (the QKV GEMM epilogue does it before its single rounding) and the
+// softmax runs "deferred max": the score accumulator is initialised with -m_ref (the running maximum BEFORE this
+// tile), so P' = exp2(acc) needs no per-score fma; when a tile raises the maximum by d > 0 the (O, l) pair is
+// multiplied by 2^-d after its P'V product -- the same sums as the classic update, with 32 VALU ops less per tile
+// and wave (the ViT shape is VALU-bound: 225 VALU instructions against 44 MFMAs per tile).
+template <int HD, int NQ, bool PRE>
+__global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : ((PRE && HD == 72) ? 3 : 2)) void attn_fwd_bf16_kernel(AttnArgs p) {
     constexpr int NT = 128 * (4 / NQ);        // threads per workgroup (always 128 query rows)
     constexpr int KS = (HD + 31) / 32;        // QK^T k-steps
     constexpr int DT = (HD + 15) / 16;        // PV d-tiles
@@ -146,8 +152,10 @@ __global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : 2) void attn_fwd_bf16
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) oacc[d][qi] = f32x4{0, 0, 0, 0};
     float m_run[NQ], l_run[NQ];
+    float m_ref[NQ];          // PRE: finite stand-in of the running maximum (0 until the first tile set it)
+    bool first_tile = true;   // PRE: the first processed tile subtracts its own maximum explicitly
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) { m_run[qi] = -INFINITY; l_run[qi] = 0.f; }
+    for (int qi = 0; qi < NQ; ++qi) { m_run[qi] = -INFINITY; l_run[qi] = 0.f; m_ref[qi] = 0.f; }
 
     int blo[NQ], bhi[NQ];
 #pragma unroll
@@ -247,10 +255,12 @@ __global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : 2) void attn_fwd_bf16
             for (int s = 0; s < KS; ++s) {
                 const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + krow * 256 + (((4 * s + g) ^ ksw) << 4));
 #pragma unroll
-                for (int qi = 0; qi < NQ; ++qi)
+                for (int qi = 0; qi < NQ; ++qi) {
+                    f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f};                               // C = 0 is an inline constant
+                    if constexpr (PRE) { const float nm = -m_ref[qi]; c0 = f32x4{nm, nm, nm, nm}; }
                     sacc[ut][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, kf), qf[qi][s],
-                        s == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[ut][qi], 0, 0, 0);   // C = 0 is an inline constant
+                        __builtin_bit_cast(bf16x8, kf), qf[qi][s], s == 0 ? c0 : sacc[ut][qi], 0, 0, 0);
+                }
             }
         }
 
@@ -258,9 +268,63 @@ __global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : 2) void attn_fwd_bf16
         // Masking (key range, causal diagonal, same-segment bias) is only evaluated on tiles that need it:
         // the test is block-uniform, so interior tiles run a compare-free body (max, fma, v_exp, add).
         bf16x8 pf[2][NQ];
+        float post_alpha[NQ];   // PRE: factor applied to (O, l) after this tile's PV product (1 = none)
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
             float sv[4][4];
+            post_alpha[qi] = 1.f;
+            if constexpr (PRE) {
+                // acc = S - m_ref (S already in log2 units). d = how far this tile's maximum exceeds m_ref.
+                float d = -INFINITY;
+                if constexpr (MASKED) {
+                    const int qloc = qrow[qi] - qs;
+#pragma unroll
+                    for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kbase + 32 * (ut >> 1) + 8 * g + 4 * (ut & 1) + r;
+                            bool valid = key < ke;
+                            if (p.causal) valid = valid && (key - ks) <= qloc + p.q_pos0;
+                            const float sc = valid ? sacc[ut][qi][r] : -INFINITY;
+                            sv[ut][r] = sc;
+                            d = fmaxf(d, sc);
+                        }
+                } else {
+#pragma unroll
+                    for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { sv[ut][r] = sacc[ut][qi][r]; d = fmaxf(d, sacc[ut][qi][r]); }
+                }
+                d = colgroup_max(d);
+                const bool saw_key = d != -INFINITY;
+                if (first_tile) {
+                    // m_ref was 0: make this tile's own maximum the reference (a row with no visible key keeps 0)
+                    const float d0 = (d == -INFINITY) ? 0.f : d;
+#pragma unroll
+                    for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sv[ut][r] -= d0;
+                    asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch, not a select chain
+                    m_ref[qi] = d0;
+                    d = 0.f;
+                }
+                float psum = 0.f;
+#pragma unroll
+                for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(sv[ut][r]);   // exp2(-inf) = 0 for masked keys
+                        sv[ut][r] = pv;
+                        if (!SUM_IN_V) psum += pv;
+                    }
+                l_run[qi] += psum;
+                if (__any(d > 0.f)) {        // this tile raised the maximum of some row of the wave
+                    const float dd = fmaxf(d, 0.f);
+                    post_alpha[qi] = __builtin_amdgcn_exp2f(-dd);
+                    m_ref[qi] += dd;
+                }
+                if (saw_key || m_run[qi] != -INFINITY) m_run[qi] = m_ref[qi];   // what the split-KV combine reads
+            } else {
             float mx = -INFINITY;
             if constexpr (MASKED) {
                 const int qloc = qrow[qi] - qs;
@@ -318,6 +382,7 @@ __global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : 2) void attn_fwd_bf16
                 l_run[qi] += psum;
             }
             m_run[qi] = m_new;
+            }   // !PRE
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 u32x4 w;
@@ -348,6 +413,17 @@ __global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : 2) void attn_fwd_bf16
                 for (int qi = 0; qi < NQ; ++qi)
                     oacc[d][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][qi], oacc[d][qi], 0, 0, 0);
             }
+        }
+        if constexpr (PRE) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                if (__any(post_alpha[qi] != 1.f)) {
+                    l_run[qi] *= post_alpha[qi];
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) oacc[d][qi] *= post_alpha[qi];
+                }
+            }
+            first_tile = false;
         }
     };
 
@@ -526,10 +602,11 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
     p.cu = a.cu_seqlens; p.row_lo = a.row_lo; p.row_hi = a.row_hi;
     p.q_len = a.q_len; p.kv_len = a.kv_len; p.hq = a.hq; p.hkv = a.hkv;
     const float LOG2E = 1.4426950408889634f;
-    p.scale_log2 = a.scale * LOG2E; p.bias_log2 = a.bias * LOG2E;
+    p.scale_log2 = a.q_prescaled ? 1.0f : a.scale * LOG2E;   // prescaled Q: scores are already in log2 units
+    p.bias_log2 = a.bias * LOG2E;
     p.q_pos0 = a.q_pos0; p.causal = a.causal;
     const int nseg = a.cu_seqlens ? a.nseg : 1;
-    p.nsplit = 1; p.gqa_pack = 0; p.part_o = nullptr; p.part_ml = nullptr;
+    p.nsplit = 1; p.gqa_pack = 0; p.q_prescaled = 0; p.part_o = nullptr; p.part_ml = nullptr;
     if (a.dtype == COGS_DT_BF16 && !a.force_rowwise && (a.head_dim == 72 || a.head_dim == 128)) {
         if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) return COGS_E_INVALID;
         const int max_len = a.cu_seqlens ? a.max_seqlen : a.q_len;
@@ -549,13 +626,22 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
         // 8 waves x 16 rows: measured faster for hd 128 (no spills, 4 waves per SIMD: causal prefill 2.58 -> 2.29 ms
         // at 15k tokens), slower for hd 72 (0.49 -> 0.52 ms: its fragment reads make the LDS the busiest unit)
         const bool light = env_nq ? env_nq == 1 : (a.head_dim == 128);
+        const bool pre = a.q_prescaled && !a.row_lo;
+        if (a.q_prescaled && a.row_lo) return COGS_E_UNSUPPORTED;   // the bias mode is parity-only and unscaled
+        p.q_prescaled = pre;
+#define COGS_ATTN_LAUNCH(HD_, NQ_, NT_)                                                                          \
+    do {                                                                                                         \
+        if (pre) hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD_, NQ_, true>), grid, dim3(NT_), 0, st, p);          \
+        else hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD_, NQ_, false>), grid, dim3(NT_), 0, st, p);             \
+    } while (0)
         if (a.head_dim == 72) {
-            if (light && !p.gqa_pack) hipLaunchKernelGGL((attn_fwd_bf16_kernel<72, 1>), grid, dim3(512), 0, st, p);
-            else hipLaunchKernelGGL((attn_fwd_bf16_kernel<72, 2>), grid, dim3(256), 0, st, p);
+            if (light && !p.gqa_pack) COGS_ATTN_LAUNCH(72, 1, 512);
+            else COGS_ATTN_LAUNCH(72, 2, 256);
         } else {
-            if (light && !p.gqa_pack) hipLaunchKernelGGL((attn_fwd_bf16_kernel<128, 1>), grid, dim3(512), 0, st, p);
-            else hipLaunchKernelGGL((attn_fwd_bf16_kernel<128, 2>), grid, dim3(256), 0, st, p);
+            if (light && !p.gqa_pack) COGS_ATTN_LAUNCH(128, 1, 512);
+            else COGS_ATTN_LAUNCH(128, 2, 256);
         }
+#undef COGS_ATTN_LAUNCH
         if (p.nsplit > 1)
             hipLaunchKernelGGL(attn_combine_kernel, dim3(a.q_len, a.hq), dim3(256), 0, st, p.part_o, p.part_ml, p.nsplit,
                                a.q_len, a.hq, a.head_dim, (bf16_t*)a.O, a.ldo);

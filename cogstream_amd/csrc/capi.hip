@@ -161,6 +161,7 @@ cogs_status cogs_attention(cogs_stream stream, const cogs_attn_desc* d) {
     a.q_len = d->q_len; a.kv_len = d->kv_len; a.hq = d->hq; a.hkv = d->hkv; a.head_dim = d->head_dim;
     a.scale = d->scale; a.causal = d->causal; a.q_pos0 = d->q_pos0; a.force_rowwise = d->force_rowwise;
     a.nsplit = d->nsplit > 1 ? d->nsplit : 1; a.ws = d->ws; a.ws_bytes = d->ws_bytes;
+    a.q_prescaled = d->q_prescaled;
     return cogs_k_attention((hipStream_t)stream, a);
 }
 
@@ -370,6 +371,10 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
         { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
     }
     const float scale = 1.0f / sqrtf((float)hd);
+    // bf16 MFMA attention kernels take Q pre-multiplied by scale*log2(e): the QKV GEMM epilogue folds the factor in
+    // before its single rounding (same relative rounding error as rounding q itself) and the softmax needs no
+    // per-score multiply. Not in the parity modes (fp32, or the eager-global bias mode).
+    const bool prescale_q = dt == COGS_DT_BF16 && attn_mode == COGS_ATTN_BLOCK_DIAG && (hd == 72 || hd == 128);
     for (int l = 0; l < w.layers; ++l) {
         const cogs_vit_layer& L = h->vit_layers[l];
         { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln1_g, L.ln1_b, (int)N, H, w.ln_eps)); }
@@ -378,6 +383,7 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
             g.A = ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = 3 * H;
             g.bias = L.qkv_b; g.M = (int)N; g.N = 3 * H; g.K = H;
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = 2 * H; g.head_dim = hd;
+            if (prescale_q) { g.q_scale = scale * 1.4426950408889634f; g.q_cols = H; }
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         {
@@ -385,6 +391,7 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
             a.Q = qkv; a.K = qkv + (size_t)H * es; a.V = qkv + (size_t)2 * H * es; a.O = att;
             a.ldq = a.ldk = a.ldv = 3 * H; a.ldo = H;
             a.q_len = (int)N; a.kv_len = (int)N; a.hq = a.hkv = w.heads; a.head_dim = hd; a.scale = scale;
+            a.q_prescaled = prescale_q;
             if (attn_mode == COGS_ATTN_REF_EAGER_GLOBAL) { a.row_lo = lo; a.row_hi = hi; a.bias = 1.0f; }
             else { a.cu_seqlens = cu; a.nseg = nframes; a.max_seqlen = max_seq; }
             { PROF(COGS_PROF_ATTN); COGS_TRY(cogs_k_attention(st, a)); }
@@ -554,6 +561,7 @@ static cogs_status llm_forward_impl(cogs_handle h, cogs_stream stream, const voi
     if (hipMemcpyAsync(x, embeds, (size_t)S * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return COGS_E_HIP;
     { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_llm_rope_table(st, rc, rs, nseg > 0 ? pos_d : nullptr, pos0, S, h->llm_inv_freq, hd / 2)); }
     const float scale = 1.0f / sqrtf((float)hd);
+    const bool prescale_q = dt == COGS_DT_BF16 && hd == 128;   // see cogs_vit_encode
     for (int l = 0; l < w.layers; ++l) {
         const cogs_llm_layer& L = h->llm_layers[l];
         const bool fuse_norm = (S == 1);   // single-token decode: RMSNorm runs inside the GEMV prologue
@@ -563,6 +571,7 @@ static cogs_status llm_forward_impl(cogs_handle h, cogs_stream stream, const voi
             g.A = fuse_norm ? x : ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = qd;
             g.bias = L.qkv_b; g.M = S; g.N = qd; g.K = H;
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = qd_q + kvd; g.head_dim = hd;
+            if (prescale_q) { g.q_scale = scale * 1.4426950408889634f; g.q_cols = qd_q; }
             if (fuse_norm) { g.rms_gamma = L.in_ln; g.rms_eps = w.rms_eps; }
             if (kv && S == 1) {   // single-token decode: the GEMV writes the new K / V row straight into the cache
                 g.kv_k = (char*)kv->k + (((size_t)l * kv->max_len) + pos0) * kvd * es;
@@ -589,7 +598,7 @@ static cogs_status llm_forward_impl(cogs_handle h, cogs_stream stream, const voi
             a.Q = qkv; a.K = kp; a.V = vp; a.O = att;
             a.ldq = qd; a.ldk = ldkv; a.ldv = ldkv; a.ldo = qd_q;
             a.q_len = S; a.kv_len = ctx; a.hq = w.heads; a.hkv = w.kv_heads; a.head_dim = hd; a.scale = scale;
-            a.causal = 1; a.q_pos0 = pos0;
+            a.causal = 1; a.q_pos0 = pos0; a.q_prescaled = prescale_q;
             if (nseg > 0) { a.cu_seqlens = cu_d; a.nseg = nseg; a.max_seqlen = max_seg; }
             if (S == 1 && dt == COGS_DT_BF16 && hd == 128) {
                 a.nsplit = llm_nsplit(ctx); a.ws = split; a.ws_bytes = split_bytes;

@@ -40,6 +40,8 @@ struct EpiArgs {
     int rope_pairs;
     int rope_cols;
     int head_dim;
+    float q_scale;              // != 1: columns < q_cols are multiplied by it after bias/rope, before the (single) rounding
+    int q_cols;                 //   (the attention kernels then take Q pre-scaled by softmax_scale*log2(e))
     int diag;                   // diagnostics only (COGS_GEMM_TRACE=2: lean path skips its store instructions)
 };
 
@@ -68,6 +70,7 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& p, int m, int n, f32x4 
         r[3] = v[3] * c[1] + v[2] * s[1];
         v = r;
     }
+    if (n < p.q_cols) v *= p.q_scale;
     if (p.act == COGS_ACT_GELU_TANH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
@@ -203,6 +206,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
                             r[3] = v[ni][3] * c[1] + v[ni][2] * sx[1];
                             v[ni] = r;
                         }
+                        if (n < p.q_cols) v[ni] *= p.q_scale;
                     }
                     if constexpr ((EPI & EPI_GELU_TANH) != 0) {
 #pragma unroll
@@ -286,6 +290,7 @@ __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bias_v[ni] = ld4_f<T>(reinterpret_cast<const T*>(bbase + (unsigned)(g4 * 8 + ni * 32)));
     }
+    const bool q_tile = nb < p.q_cols;   // wave-uniform (epilogue_wave sends tiles straddling q_cols to the general path)
     const char* csbase = nullptr;
     unsigned cs_lane[4] = {0, 0, 0, 0};
     long cs_row16 = 0;
@@ -334,6 +339,7 @@ __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int
                     q[2] = v[ni][2] * t[2] - v[ni][3] * t[3];
                     q[3] = v[ni][3] * t[2] + v[ni][2] * t[3];
                     v[ni] = q;
+                    if (q_tile) v[ni] *= p.q_scale;
                 }
                 if constexpr ((EPI & EPI_GELU_TANH) != 0) {
 #pragma unroll
@@ -374,7 +380,8 @@ __device__ __forceinline__ void epilogue_wave(const EpiArgs& p, int mb, int nb, 
                     (reinterpret_cast<unsigned long>(p.C) & 15) == 0;
         if constexpr ((EPI & EPI_RES) != 0) fast = fast && (p.ldr & 7) == 0 && (reinterpret_cast<unsigned long>(p.R) & 15) == 0;
         if constexpr ((EPI & EPI_ROPE) != 0) {
-            fast = fast && p.rope_sin == nullptr && p.head_dim >= 64 && (nb + 64 <= p.rope_cols || nb >= p.rope_cols);
+            fast = fast && p.rope_sin == nullptr && p.head_dim >= 64 && (nb + 64 <= p.rope_cols || nb >= p.rope_cols) &&
+                   (nb + 64 <= p.q_cols || nb >= p.q_cols);
             if (fast) {
                 if (nb < p.rope_cols) epilogue_tile_fast<EPI>(p, mb, nb, lane, acc);
                 else epilogue_tile_fast<(EPI & ~EPI_ROPE)>(p, mb, nb, lane, acc);
@@ -390,6 +397,7 @@ __device__ __forceinline__ void epilogue_wave(const EpiArgs& p, int mb, int nb, 
 inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {
     if (g.act == COGS_ACT_SWIGLU && (g.bias || g.residual || g.out_f32)) return COGS_E_INVALID;
     if (g.rope_cos && (g.head_dim <= 0 || g.head_dim % 4 != 0 || g.rope_cols % g.head_dim != 0)) return COGS_E_INVALID;
+    if (g.q_scale != 1.f && (!g.rope_cos || g.q_cols % 4 != 0 || g.q_cols > g.rope_cols)) return COGS_E_INVALID;   // rope epilogues only
     e->C = (char*)g.C; e->ldc = g.ldc;
     e->bias = g.bias;
     e->R = (const char*)g.residual; e->ldr = g.ldr;
@@ -397,6 +405,7 @@ inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {
     e->rope_cos = g.rope_cos; e->rope_sin = g.rope_sin;
     e->rope_pairs = g.head_dim / 2; e->rope_cols = g.rope_cols;
     e->head_dim = g.head_dim > 0 ? g.head_dim : 4;
+    e->q_scale = g.q_scale; e->q_cols = g.q_scale != 1.f ? g.q_cols : 0;
     e->diag = 0;
     return COGS_OK;
 }

@@ -55,6 +55,7 @@ __device__ __forceinline__ void epilogue2(const EpiArgs& p, int n, float v0, flo
         const float r1 = v1 * c + v0 * sn;
         v0 = r0; v1 = r1;
     }
+    if (n < p.q_cols) { v0 *= p.q_scale; v1 *= p.q_scale; }
     if (p.act == COGS_ACT_GELU_TANH) { v0 = gelu_tanh_f(v0); v1 = gelu_tanh_f(v1); }
     else if (p.act == COGS_ACT_GELU_ERF) { v0 = gelu_erf_f(v0); v1 = gelu_erf_f(v1); }
     else if (p.act == COGS_ACT_SWIGLU) {

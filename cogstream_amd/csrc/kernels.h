@@ -31,6 +31,8 @@ struct CogsGemm {
     // M == 1 only: output columns [kv_col0, kv_col0 + kv_dim) go to kv_k[0..kv_dim), the next kv_dim to kv_v
     // (single-token decode writes the new K/V row straight into the cache; no kv_append launch)
     void* kv_k = nullptr; void* kv_v = nullptr; int kv_col0 = 0; int kv_dim = 0;
+    // rope epilogues only: columns [0, q_cols) (the Q heads) are multiplied by q_scale before rounding
+    float q_scale = 1.f; int q_cols = 0;
 };
 int cogs_k_gemm(hipStream_t st, const CogsGemm& g);
 
@@ -53,6 +55,7 @@ struct CogsAttn {
     int nsplit = 1;                   // >1: split the keys over blocks (decode); needs ws
     void* ws = nullptr;               // nsplit*q_len*hq*(head_dim+2) floats
     size_t ws_bytes = 0;
+    int q_prescaled = 0;              // Q already multiplied by scale*log2(e) (bf16 MFMA kernels only; no bias mode)
 };
 int cogs_k_attention(hipStream_t st, const CogsAttn& a);
 

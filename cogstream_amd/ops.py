@@ -63,7 +63,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hq: int, hkv
               scale: Optional[float] = None, cu_seqlens: Optional[torch.Tensor] = None, max_seqlen: int = 0,
               row_lo: Optional[torch.Tensor] = None, row_hi: Optional[torch.Tensor] = None, bias: float = 0.0,
               causal: bool = False, q_pos0: int = 0, force_rowwise: bool = False, nsplit: int = 1,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, q_prescaled: bool = False) -> torch.Tensor:
     """token-major attention: q [Lq, hq*hd] (may be a column view of a fused buffer), k/v [Lk, hkv*hd]"""
     _need_cuda(q, k, v)
     Lq, Lk = q.shape[0], k.shape[0]
@@ -82,6 +82,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hq: int, hkv
     d.scale = scale if scale is not None else 1.0 / math.sqrt(head_dim)
     d.causal, d.q_pos0 = int(causal), q_pos0
     d.force_rowwise = int(force_rowwise)
+    d.q_prescaled = int(q_prescaled)
     ws = None
     if nsplit > 1:
         ws = torch.empty(nsplit * Lq * hq * (head_dim + 2), device=q.device, dtype=torch.float32)

@@ -117,6 +117,8 @@ typedef struct {
     int causal; int q_pos0;
     int force_rowwise;      /* use the generic fp32-math kernel (any head_dim <= 256) */
     int nsplit; void* ws; size_t ws_bytes;
+    int q_prescaled;        /* Q already carries scale*log2(e) (`scale` is then ignored): lets the bf16 kernels run the
+                             * softmax without a per-score multiply; not with row_lo/row_hi */
 } cogs_attn_desc;
 cogs_status cogs_attention(cogs_stream stream, const cogs_attn_desc* d);
 

@@ -118,12 +118,12 @@ def test_gemm_rope_epilogue(dev, M, heads, interleaved):
     assert rel_err(out.float().view(M, 3 * heads, hd), refp) < 1.2e-2
 
 
-def _attn_ref(q, k, v, hq, hkv, hd, cu=None, causal=False, q_pos0=0, row_lo=None, row_hi=None, bias=0.0):
+def _attn_ref(q, k, v, hq, hkv, hd, cu=None, causal=False, q_pos0=0, row_lo=None, row_hi=None, bias=0.0, scale=None):
     Lq, Lk = q.shape[0], k.shape[0]
     q = q.float().view(Lq, hq, hd).transpose(0, 1)
     k = k.float().view(Lk, hkv, hd).transpose(0, 1).repeat_interleave(hq // hkv, 0)
     v = v.float().view(Lk, hkv, hd).transpose(0, 1).repeat_interleave(hq // hkv, 0)
-    s = q @ k.transpose(1, 2) / math.sqrt(hd)
+    s = q @ k.transpose(1, 2) * (1.0 / math.sqrt(hd) if scale is None else scale)
     qi, kj = torch.arange(Lq)[:, None], torch.arange(Lk)[None, :]
     allow = torch.ones(Lq, Lk, dtype=torch.bool)
     if cu is not None:
@@ -151,6 +151,49 @@ def test_attention_block_diag_bf16(dev, hd, heads, lens):
     out = ops.attention(g[:, :H], g[:, H:2 * H], g[:, 2 * H:], hq=heads, hkv=heads, head_dim=hd,
                         cu_seqlens=cu.to(dev), max_seqlen=max(lens))
     assert rel_err(out.float(), ref) < 1.5e-2
+
+
+LOG2E = 1.4426950408889634
+
+
+@pytest.mark.parametrize("hd,heads,lens", [(72, 2, [256, 256]), (72, 2, [924]), (72, 1, [37, 130]), (128, 2, [300, 64])])
+def test_attention_prescaled_q_block_diag(dev, hd, heads, lens):
+    """q_prescaled: Q carries scale*log2(e) (rounded to bf16 once, as the QKV GEMM epilogue does) and the kernel
+    runs the deferred-max softmax; the reference is the plain softmax of the same rounded Q with scale ln 2"""
+    ops = _ops()
+    torch.manual_seed(sum(lens) + hd)
+    n = sum(lens)
+    H = heads * hd
+    qkv = torch.randn(n, 3 * H)
+    qkv[:, :H] *= LOG2E / math.sqrt(hd)
+    # rows whose scores move by tens of log2 units from tile to tile exercise the rebase path
+    qkv[5, :H] *= 6.0
+    qkv = qkv.bfloat16()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    ref = _attn_ref(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], heads, heads, hd, cu=cu.long(), scale=math.log(2.0))
+    g = qkv.to(dev)
+    out = ops.attention(g[:, :H], g[:, H:2 * H], g[:, 2 * H:], hq=heads, hkv=heads, head_dim=hd,
+                        cu_seqlens=cu.to(dev), max_seqlen=max(lens), q_prescaled=True)
+    assert rel_err(out.float(), ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("S,pos0", [(200, 0), (130, 77), (1, 300), (1, 5000)])
+def test_attention_prescaled_q_causal_gqa(dev, S, pos0):
+    ops = _ops()
+    torch.manual_seed(S + 1)
+    hd, hq, hkv = 128, 4, 2
+    ctx = pos0 + S
+    q = (torch.randn(S, hq * hd) * (LOG2E / math.sqrt(hd))).bfloat16()
+    k = torch.randn(ctx, hkv * hd).bfloat16()
+    v = torch.randn(ctx, hkv * hd).bfloat16()
+    ref = _attn_ref(q, k, v, hq, hkv, hd, causal=True, q_pos0=pos0, scale=math.log(2.0))
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_pos0=pos0,
+                        q_prescaled=True)
+    assert rel_err(out.float(), ref) < 1.5e-2
+    if S == 1:
+        out2 = ops.attention(q.to(dev), k.to(dev), v.to(dev), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_pos0=pos0,
+                             nsplit=3 if pos0 < 1000 else 20, q_prescaled=True)
+        assert rel_err(out2.float(), ref) < 1.5e-2
 
 
 def test_attention_integer_exact(dev):

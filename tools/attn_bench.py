@@ -14,9 +14,15 @@ bf = torch.bfloat16
 cases = []
 
 
+PRE = os.environ.get("ATTN_PRE") == "1"      # Q pre-multiplied by scale*log2(e), deferred-max softmax kernels
+
+
 def vit_case(nseg, seglen, heads=16, hd=72):
     L = nseg * seglen
-    qkv = torch.randn(L, 3 * heads * hd, device=dev).to(bf)
+    qkv = torch.randn(L, 3 * heads * hd, device=dev)
+    if PRE:
+        qkv[:, :heads * hd] *= 1.4426950408889634 / hd ** 0.5
+    qkv = qkv.to(bf)
     cu = torch.arange(0, L + 1, seglen, device=dev, dtype=torch.int32)
     out = torch.empty(L, heads * hd, device=dev, dtype=bf)
     H = heads * hd
@@ -24,19 +30,19 @@ def vit_case(nseg, seglen, heads=16, hd=72):
 
     def run():
         ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], hq=heads, hkv=heads, head_dim=hd, cu_seqlens=cu,
-                      max_seqlen=seglen, out=out)
+                      max_seqlen=seglen, out=out, q_prescaled=PRE)
     return (f"vit hd{hd} {nseg}x{seglen}", run, fl)
 
 
 def llm_case(S, hq=28, hkv=4, hd=128):
-    q = torch.randn(S, hq * hd, device=dev).to(bf)
+    q = (torch.randn(S, hq * hd, device=dev) * (1.4426950408889634 / hd ** 0.5 if PRE else 1.0)).to(bf)
     k = torch.randn(S, hkv * hd, device=dev).to(bf)
     v = torch.randn(S, hkv * hd, device=dev).to(bf)
     out = torch.empty(S, hq * hd, device=dev, dtype=bf)
     fl = 4.0 * hq * S * S * hd / 2
 
     def run():
-        ops.attention(q, k, v, hq=hq, hkv=hkv, head_dim=hd, causal=True, out=out)
+        ops.attention(q, k, v, hq=hq, hkv=hkv, head_dim=hd, causal=True, out=out, q_prescaled=PRE)
     return (f"llm hd{hd} causal S={S}", run, fl)
 
 
