@@ -291,6 +291,8 @@ __global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : ((PRE && HD == 72) ? 
                         }
                 } else {
 #pragma unroll
+                    // (an inline-asm v_max3_f32 would save the canonicalising v_max hipcc puts in front of fmaxf on MFMA
+                    // results, but asm operands get no MFMA->VALU hazard nops: measured wrong maxima. Left to hipcc.)
                     for (int ut = 0; ut < 4; ++ut)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { sv[ut][r] = sacc[ut][qi][r]; d = fmaxf(d, sacc[ut][qi][r]); }
