@@ -361,11 +361,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x128_kernel(GemmArgs p) {
 //     --- s_barrier ---
 // and group 1 runs ONE BARRIER BEHIND group 0, so on every SIMD one wave is in its C segment while the
 // other is in its L segment: the matrix pipe never waits for LDS/DMA issue. Persistent over tiles with
-// a continuous K-tile stream (prefetch distance 3 K-tiles, counted vmcnt(8) once per K-tile).
+// a continuous K-tile stream (prefetch distance 3 K-tiles, one counted vmcnt per K-tile). In-kernel interval stamps
+// (-DCOGS_GEMM_KSTAMPS build, tools/gemm_trace.py): per K-tile the L segments take 330-440 cycles against 258 for a
+// C segment, i.e. the two LDS-DMA issues + fragment reads of a phase, not the MFMAs, set the interval; a 5-slot ring
+// (distance 4) and `buffer_load ... lds` pieces instead of `global_load_lds` were both measured without gain.
 constexpr int BM3 = 256, BN3 = 256;
 constexpr int ROW3 = 64;                          // bytes per LDS row = 32 bf16
 constexpr int SLOT3 = (BM3 + BN3) * ROW3;         // 32 KiB per K-tile
-constexpr int RING3 = 4;
+constexpr int RING3 = 4;                          // ring slots (5 = all 160 KiB of LDS: measured, no gain)
+constexpr int DIST3 = RING3 - 1;                  // prefetch distance in K-tiles
 #ifndef PP_TAIL
 #define PP_TAIL 0   // MFMA rows (x4 MFMAs) of a C segment issued after its closing barrier (1: measured 10 % slower -- the L segment, not the barrier round trip, is what an interval waits for)
 #endif
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
         glds16(src[2 * h] + ko, dst + (2 * h) * 1024);
         glds16(src[2 * h + 1] + ko, dst + (2 * h + 1) * 1024);
         if (h == 1) {
-            st_slot = (st_slot + 1) & 3;
+            st_slot = st_slot + 1 == RING3 ? 0 : st_slot + 1;
             if (++st_kt == KT) {
                 st_kt = 0;
                 st_t += gridDim.x;
@@ -442,11 +446,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
     set_src(st_t);
     const int my_tiles = (nb - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
     const int total = my_tiles * KT;          // K-tiles this workgroup consumes
-    // prologue: K-tiles 0..2 in flight (4 pieces each), K-tile 0 landed
+    // prologue: K-tiles 0..DIST3-1 in flight (4 pieces each), K-tile 0 landed
     {
-        int pre = total < 3 ? total : 3;
+        int pre = total < DIST3 ? total : DIST3;
         for (int i = 0; i < pre; ++i) { stage_half(0); stage_half(1); }
-        if (pre == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (pre >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (pre == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (pre == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -463,9 +468,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
     constexpr bool WIDE_EPI = (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0;
     int epi_stores = 0;
     auto wait_next_ktile = [&](int ahead, int kt) {
-        const bool relaxed = epi_stores == 16 && kt < 2;
-        if (ahead >= 3) { if (relaxed) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else if (ahead == 2) { if (relaxed) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        // K-tile g+1 has landed when at most the pieces of the K-tiles staged after it are outstanding:
+        // min(ahead, DIST3) - 1 K-tiles of 4 pieces, plus the 16 epilogue stores while they are still newer than it
+        const bool relaxed = epi_stores == 16 && kt < DIST3 - 1;
+        const int newer = (ahead < DIST3 ? ahead : DIST3) - 1;
+        if (newer >= 3) { if (relaxed) asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+        else if (newer == 2) { if (relaxed) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else if (newer == 1) { if (relaxed) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else { if (relaxed) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     };
 
@@ -490,6 +499,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         stamp();
+#ifdef COGS_GEMM_KSTAMPS
+        // diagnostic build only: where does an interval go? sums over the K-tiles of this tile, per wave group
+        unsigned long long ks_L0 = 0, ks_W0 = 0, ks_C0 = 0, ks_X0 = 0, ks_L1 = 0, ks_W1 = 0, ks_C1 = 0, ks_X1 = 0;
+        unsigned long long ks_prev = __builtin_amdgcn_s_memtime();
+#define KSTAMP(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - ks_prev; ks_prev = now_; } while (0)
+#else
+#define KSTAMP(acc_) do {} while (0)
+#endif
         for (int kt = 0; kt < KT; ++kt, ++g) {
             const char* base = smem + slot * SLOT3;
             // ---- phase 0: L segment ----
@@ -505,7 +522,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(afr[0]), "+v"(afr[1]), "+v"(afr[2]), "+v"(afr[3]), "+v"(wfr[0]), "+v"(wfr[1]),
                          "+v"(wfr[2]), "+v"(wfr[3]));
+            KSTAMP(ks_L0);
             __builtin_amdgcn_s_barrier();
+            KSTAMP(ks_W0);
             // ---- phase 0: C segment ----
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -517,7 +536,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
             // hand the matrix pipe over EARLY: the other group is released while this wave's last PP_TAIL*4 MFMAs are
             // still queued, so the pipe does not drain for a barrier round trip every interval
             __builtin_amdgcn_sched_barrier(0);
+            KSTAMP(ks_C0);
             __builtin_amdgcn_s_barrier();
+            KSTAMP(ks_X0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = 4 - PP_TAIL; mi < 4; ++mi)
@@ -539,7 +560,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
             // group 1 here (end of its L segment), group 0 at the end of its C segment below.
             const int ahead = total - 1 - g;   // K-tiles after the current one
             if (grp == 1) wait_next_ktile(ahead, kt);
+            KSTAMP(ks_L1);
             __builtin_amdgcn_s_barrier();
+            KSTAMP(ks_W1);
             // ---- phase 1: C segment ----
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -550,7 +573,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
                         __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[1][mi][ni], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (grp == 0) wait_next_ktile(ahead, kt);
+            KSTAMP(ks_C1);
             __builtin_amdgcn_s_barrier();
+            KSTAMP(ks_X1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mi = 4 - PP_TAIL; mi < 4; ++mi)
@@ -560,8 +585,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
                         __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[1][mi][ni], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             asm volatile("" ::: "memory");
-            slot = (slot + 1) & 3;
+            slot = slot + 1 == RING3 ? 0 : slot + 1;
         }
+#ifdef COGS_GEMM_KSTAMPS
+        if (tracing && lane == 0 && t == (int)blockIdx.x) {   // first tile of workgroup 0
+            unsigned long long* o = p.trace + 192 + grp * 8;
+            o[0] = ks_L0; o[1] = ks_W0; o[2] = ks_C0; o[3] = ks_X0; o[4] = ks_L1; o[5] = ks_W1; o[6] = ks_C1; o[7] = ks_X1;
+        }
+#endif
         // epilogue of this tile; it runs inside this group's next L interval, i.e. beside the other group's C
         stamp();
         epilogue_wave<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0]);
@@ -613,13 +644,13 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
     static const bool env_trace = getenv("COGS_GEMM_TRACE") != nullptr;
     if (env_trace) {
         static unsigned long long* dbuf = nullptr;
-        if (!dbuf) (void)hipMalloc(&dbuf, 192 * 8);
-        (void)hipMemsetAsync(dbuf, 0, 192 * 8, st);
+        if (!dbuf) (void)hipMalloc(&dbuf, 208 * 8);
+        (void)hipMemsetAsync(dbuf, 0, 208 * 8, st);
         GemmArgs q = p;
         q.trace = dbuf;
         q.epi.diag = atoi(getenv("COGS_GEMM_TRACE"));
         hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, q);
-        unsigned long long h[192];
+        unsigned long long h[208];
         (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
         for (int g = 0; g < 2; ++g) {
@@ -629,6 +660,14 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
                         h[g * 96 + i + 3] - h[g * 96 + i + 2]);
             fprintf(stderr, "\n");
         }
+#ifdef COGS_GEMM_KSTAMPS
+        for (int g = 0; g < 2; ++g) {
+            const unsigned long long* o = h + 192 + g * 8;
+            const double kt_n = p.K / 32.0;
+            fprintf(stderr, "[gemm kstamps] group %d per K-tile: phase0 L %.0f wait %.0f C %.0f wait %.0f | phase1 L %.0f wait %.0f C %.0f wait %.0f\n",
+                    g, o[0] / kt_n, o[1] / kt_n, o[2] / kt_n, o[3] / kt_n, o[4] / kt_n, o[5] / kt_n, o[6] / kt_n, o[7] / kt_n);
+        }
+#endif
         return;
     }
     hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, p);

@@ -11,10 +11,15 @@ from cogstream_amd import _lib as L  # noqa: E402
 from cogstream_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-M = 59136
+which = sys.argv[1] if len(sys.argv) > 1 else "vit"
+M = 59136 if which == "vit" else 15396
 bf = torch.bfloat16
-for name, N, K, kw in [("qkv plain", 3456, 1152, {}), ("fc1 plain", 4352, 1152, {}),
-                       ("fc1 gelu", 4352, 1152, dict(bias=True, act=L.ACT_GELU_TANH)), ("fc2 res", 1152, 4352, dict(res=True))]:
+shapes = ([("qkv plain", 3456, 1152, {}), ("fc1 plain", 4352, 1152, {}),
+           ("fc1 gelu", 4352, 1152, dict(bias=True, act=L.ACT_GELU_TANH)), ("fc2 res", 1152, 4352, dict(res=True))]
+          if which == "vit" else
+          [("gate/up swiglu", 37888, 3584, dict(act=L.ACT_SWIGLU)), ("gate/up plain", 37888, 3584, {}),
+           ("down res", 3584, 18944, dict(res=True))])
+for name, N, K, kw in shapes:
     a = (torch.rand(M, K, device=dev) - 0.5).to(bf)
     w = ((torch.rand(N, K, device=dev) - 0.5) * 0.05).to(bf)
     args = {}
@@ -24,6 +29,7 @@ for name, N, K, kw in [("qkv plain", 3456, 1152, {}), ("fc1 plain", 4352, 1152, 
         args["residual"] = torch.zeros(M, N, device=dev, dtype=bf)
     if kw.get("act"):
         args["act"] = kw["act"]
+    os.environ["COGS_GEMM_NOSPLIT"] = "1"
     print("==", name, file=sys.stderr)
     for _ in range(2):
         ops.gemm(a, w, **args)
