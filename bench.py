@@ -192,12 +192,12 @@ def main() -> None:
         # HBM-side traffic per GEMM launch: PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 read
         # correction) collected with tools/collect_profiles.sh and committed under profiles/
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_c_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r1_d_gemm_traffic.json")
         if world == 1 and T == 64 and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")
         out["roofline"] = {"bound": "mfma",
-                           "kernel": "bf16 MFMA GEMM (gemm_tn_pp_kernel<*> + gemm_tn_256x128_kernel<*>, every "
-                                     "encoder+projector GEMM launch of one step)",
+                           "kernel": "bf16 MFMA GEMM (gemm_tn_pp_kernel<*> + gemm_tn_256x128_kernel<*>: every encoder+"
+                                     "projector GEMM kernel of one step; a round-aligned split counts as two launches)",
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                            "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),

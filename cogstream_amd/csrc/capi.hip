@@ -33,14 +33,16 @@ struct cogs_ctx {
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;      // pairs
     std::vector<int> prof_cls;
+    std::vector<int> prof_n;              // kernels inside the bracket
     size_t prof_used = 0;
 };
 
 // RAII event bracket around one launch; a no-op unless cogs_profile_begin() was called
 struct ProfScope {
-    cogs_ctx* c; hipStream_t st; size_t slot = 0; bool on;
+    cogs_ctx* c; hipStream_t st; size_t slot = 0; bool on; long launches0 = 0;
     ProfScope(cogs_ctx* c_, hipStream_t st_, int cls) : c(c_), st(st_), on(c_->prof_on) {
         if (!on) return;
+        launches0 = cogs_k_gemm_launch_count();
         if (c->prof_used * 2 + 2 > c->prof_ev.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
@@ -51,7 +53,13 @@ struct ProfScope {
         c->prof_cls[slot] = cls;
         (void)hipEventRecord(c->prof_ev[2 * slot], st);
     }
-    ~ProfScope() { if (on) (void)hipEventRecord(c->prof_ev[2 * slot + 1], st); }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(c->prof_ev[2 * slot + 1], st);
+        const long n = cogs_k_gemm_launch_count() - launches0;   // a GEMM bracket may hold two kernels (split)
+        if (c->prof_n.size() < c->prof_used) c->prof_n.resize(c->prof_used);
+        c->prof_n[slot] = n > 0 ? (int)n : 1;
+    }
 };
 #define PROF(cls) ProfScope _prof_scope(h, st, cls)
 
@@ -129,7 +137,7 @@ cogs_status cogs_profile_end(cogs_handle h, cogs_stream stream, float* ms_per_cl
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) != hipSuccess) return COGS_E_HIP;
         const int cls = h->prof_cls[i];
-        if (cls >= 0 && cls < COGS_PROF_CLASSES) { ms_per_class[cls] += ms; launches_per_class[cls] += 1; }
+        if (cls >= 0 && cls < COGS_PROF_CLASSES) { ms_per_class[cls] += ms; launches_per_class[cls] += i < h->prof_n.size() ? h->prof_n[i] : 1; }
     }
     h->prof_used = 0;
     return COGS_OK;

@@ -607,6 +607,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
 
 }  // namespace
 
+// kernel launches issued by cogs_k_gemm on this thread (a round-aligned split is two): lets the profiler bracket
+// report per-KERNEL averages that can be compared with rocprofv3's kernel stats
+static thread_local long g_gemm_launches = 0;
+long cogs_k_gemm_launch_count() { return g_gemm_launches; }
+
 int cogs_k_gemv(hipStream_t st, const CogsGemm& g);
 
 namespace {
@@ -619,6 +624,7 @@ void launch_small(hipStream_t st, const GemmArgs& p, int grid) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
+    ++g_gemm_launches;
     hipLaunchKernelGGL((gemm_tn_kernel<T, EPI>), dim3(grid), dim3(256), lds, st, p);
 }
 template <typename T, int EPI>
@@ -631,6 +637,7 @@ void launch_big(hipStream_t st, const GemmArgs& p, int grid) {
     }
     static const int env_wgs = getenv("COGS_GEMM_WGS") ? atoi(getenv("COGS_GEMM_WGS")) : PERSISTENT_WGS;
     const int wgs = env_wgs <= 0 ? grid : (grid < env_wgs ? grid : env_wgs);   // 0 = one tile per workgroup
+    ++g_gemm_launches;
     hipLaunchKernelGGL((gemm_tn_256x128_kernel<T, EPI>), dim3(wgs), dim3(512), lds, st, p);
 }
 template <int EPI>
@@ -670,6 +677,7 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
 #endif
         return;
     }
+    ++g_gemm_launches;
     hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, p);
 }
 void dispatch_pp(hipStream_t st, const GemmArgs& p, int grid, int mask) {
@@ -717,7 +725,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return COGS_E_INVALID;
     if (g.K % BK != 0 || g.N % 4 != 0) return COGS_E_INVALID;
     if ((g.lda * es) % 16 != 0 || (g.ldw * es) % 16 != 0) return COGS_E_INVALID;
-    if (g.M == 1) return cogs_k_gemv(st, g);
+    if (g.M == 1) { ++g_gemm_launches; return cogs_k_gemv(st, g); }
     if (g.rms_gamma) return COGS_E_UNSUPPORTED;   // fused RMSNorm exists for the single-token GEMV only
     GemmArgs p;
     p.trace = nullptr;
