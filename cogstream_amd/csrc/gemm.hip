@@ -655,7 +655,6 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         (void)hipMemsetAsync(dbuf, 0, 208 * 8, st);
         GemmArgs q = p;
         q.trace = dbuf;
-        q.epi.diag = atoi(getenv("COGS_GEMM_TRACE"));
         hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, q);
         unsigned long long h[208];
         (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, st);

@@ -42,7 +42,6 @@ struct EpiArgs {
     int head_dim;
     float q_scale;              // != 1: columns < q_cols are multiplied by it after bias/rope, before the (single) rounding
     int q_cols;                 //   (the attention kernels then take Q pre-scaled by softmax_scale*log2(e))
-    int diag;                   // diagnostics only (COGS_GEMM_TRACE=2: lean path skips its store instructions)
 };
 
 // (cos, sin) of the two rotary pairs pi, pi+1 of row m, from either table format
@@ -364,8 +363,7 @@ __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int
                 const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
                 const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                if (p.diag != 2) *reinterpret_cast<u32x4*>(cbase + mi * c_row16 + c_lane + 64 * pr) = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                else asm volatile("" ::"v"(s0), "v"(s1));
+                *reinterpret_cast<u32x4*>(cbase + mi * c_row16 + c_lane + 64 * pr) = u32x4{s0[0], s1[0], s0[1], s1[1]};
             }
         }
     }
@@ -406,7 +404,6 @@ inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {
     e->rope_pairs = g.head_dim / 2; e->rope_cols = g.rope_cols;
     e->head_dim = g.head_dim > 0 ? g.head_dim : 4;
     e->q_scale = g.q_scale; e->q_cols = g.q_scale != 1.f ? g.q_cols : 0;
-    e->diag = 0;
     return COGS_OK;
 }
 
