@@ -65,6 +65,18 @@ def run_session(model, processor, segments: Sequence[Dict[str, Any]], system: st
     return records
 
 
+def save_to_json(video_name: str, data, folder_path: str) -> str:
+    """evaluate/answer_generate.py:30-35 -- the result file the reference's eval_metrics reads:
+    {"video_name": ..., "Data": [[record, ...]]} with one inner list per query chain"""
+    import json
+    import os
+    os.makedirs(folder_path, exist_ok=True)
+    file_path = os.path.join(folder_path, f"{video_name}.json")
+    with open(file_path, "w", encoding="utf-8") as f:
+        json.dump({"video_name": video_name, "Data": data}, f, ensure_ascii=False, indent=4)
+    return file_path
+
+
 def shard_videos(n_videos: int, rank: int, world: int) -> List[int]:
     """DistributedSampler(shuffle=False)-style round robin with padding by wrap-around (:186)"""
     per = -(-n_videos // world)

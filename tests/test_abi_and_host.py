@@ -121,3 +121,14 @@ def test_pillow_resample_restatement_is_bit_exact():
         f = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         ref = np.asarray(Image.fromarray(f).resize((tw, th), resample=Image.BICUBIC))
         assert np.array_equal(pr.resize_bicubic_exact(f, (th, tw)), ref), (h, w, th, tw)
+
+
+def test_result_json_layout(tmp_path):
+    """the on-disk result format of evaluate/answer_generate.py:30-35,143 (what eval_metrics consumes)"""
+    import json
+    from cogstream_amd.answer_generate import save_to_json
+    recs = [{"qa_id": 0, "question": "q", "answer": "a", "prediction": "p\u00e9", "predicted_coi": [], "predicted_visual": True, "coi": []}]
+    path = save_to_json("clip_007", [recs], str(tmp_path / "out"))
+    d = json.load(open(path, encoding="utf-8"))
+    assert path.endswith("clip_007.json") and d == {"video_name": "clip_007", "Data": [recs]}
+    assert "p\u00e9" not in open(path, encoding="utf-8").read()      # ensure_ascii=False like the reference
