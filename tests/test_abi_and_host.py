@@ -131,4 +131,5 @@ def test_result_json_layout(tmp_path):
     path = save_to_json("clip_007", [recs], str(tmp_path / "out"))
     d = json.load(open(path, encoding="utf-8"))
     assert path.endswith("clip_007.json") and d == {"video_name": "clip_007", "Data": [recs]}
-    assert "p\u00e9" not in open(path, encoding="utf-8").read()      # ensure_ascii=False like the reference
+    text = open(path, encoding="utf-8").read()
+    assert "\\u00e9" not in text and "\u00e9" in text               # ensure_ascii=False like the reference
