@@ -595,10 +595,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
 #endif
         // epilogue of this tile; it runs inside this group's next L interval, i.e. beside the other group's C
         stamp();
-        epilogue_wave<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0]);
-        if (tracing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         stamp();
-        epilogue_wave<T, EPI>(p.epi, m0 + grp * 128 + 64, n0 + wc * 64, p.M, p.N, lane, acc[1]);
+        epilogue_wave_pair<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0], acc[1]);
         stamp();
         epi_stores = (WIDE_EPI && (p.N & 31) == 0 && m0 + BM3 <= p.M && n0 + BN3 <= p.N) ? 16 : 0;
     }

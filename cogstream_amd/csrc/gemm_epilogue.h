@@ -392,6 +392,163 @@ __device__ __forceinline__ void epilogue_wave(const EpiArgs& p, int mb, int nb, 
     epilogue_tile<T, EPI>(p, mb, nb, M, N, lane, acc);
 }
 
+// The ping-pong kernel's wave region (128 rows x 64 columns = acc0 | acc1) as FOUR 32-row batches, software-
+// pipelined: the loads of batch b+2 (residual rows / rotary pairs) are issued BEFORE the stores of batch b. vmcnt
+// counts loads and stores in one in-order queue, so in the plain per-half sequence (load, wait, math, store, load,
+// ...) every wait for a load also waits for the stores issued before it -- a store round trip plus a load round trip
+// per batch, which is what made the rope / residual epilogues cost 20-25 % of a K = 1152 tile.
+template <int EPI>
+__device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int nb, int lane, f32x4 (&acc0)[4][4],
+                                                   f32x4 (&acc1)[4][4]) {
+    typedef bf16_t T;
+    const int r = lane & 15, g4 = lane >> 4;
+    const int wcol = 16 * (g4 & 1) + 8 * (g4 >> 1);
+    char* const cbase = p.C + ((long)mb * p.ldc + nb) * 2;
+    const unsigned c_lane = ((unsigned)r * (unsigned)p.ldc + (unsigned)wcol) * 2u;
+    const long c_row16 = p.ldc * 32;
+    const char* rbase = nullptr;
+    unsigned r_lane = 0;
+    long r_row16 = 0;
+    if constexpr ((EPI & EPI_RES) != 0) {
+        rbase = p.R + ((long)mb * p.ldr + nb) * 2;
+        r_lane = ((unsigned)r * (unsigned)p.ldr + (unsigned)wcol) * 2u;
+        r_row16 = p.ldr * 32;
+    }
+    f32x4 bias_v[4];
+    if constexpr ((EPI & EPI_BIAS) != 0) {
+        const char* bbase = reinterpret_cast<const char*>(p.bias) + (long)nb * 2;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bias_v[ni] = ld4_f<T>(reinterpret_cast<const T*>(bbase + (unsigned)(g4 * 8 + ni * 32)));
+    }
+    const bool q_tile = nb < p.q_cols;
+    const char* csbase = nullptr;
+    unsigned cs_lane[4] = {0, 0, 0, 0};
+    long cs_row16 = 0;
+    if constexpr ((EPI & EPI_ROPE) != 0) {
+        csbase = reinterpret_cast<const char*>(p.rope_cos) + (long)mb * p.rope_pairs * 8;
+        cs_row16 = (long)p.rope_pairs * 128;
+        const int nbmod = nb % p.head_dim;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            int c = nbmod + 16 * ni + 4 * g4;
+            c -= c >= p.head_dim ? p.head_dim : 0;
+            cs_lane[ni] = (unsigned)(r * p.rope_pairs * 8 + c * 4);
+        }
+    }
+    // batch = RB row blocks of 16 rows: 2 (32 rows, 4 batches) normally, 1 (8 batches) with rotary loads, whose
+    // 16 registers per row block would otherwise push the kernel into spills
+    constexpr int RB = (EPI & EPI_ROPE) != 0 ? 1 : 2;
+    constexpr int NB = 8 / RB;
+    u32x4 res_wide[NB][RB][2];   // [batch][row block of the batch][tile pair]
+    f32x4 cs4[NB][RB][4];
+    auto load_batch = [&](const int b) {
+        if constexpr ((EPI & EPI_RES) != 0) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+                    res_wide[b][i][pr] = *reinterpret_cast<const u32x4*>(rbase + (RB * b + i) * r_row16 + r_lane + 64 * pr);
+        }
+        if constexpr ((EPI & EPI_ROPE) != 0) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    cs4[b][i][ni] = *reinterpret_cast<const f32x4*>(csbase + (RB * b + i) * cs_row16 + cs_lane[ni]);
+        }
+    };
+    u32x4 outv[RB][2];
+    auto math_batch = [&](const int b) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int blk = RB * b + i;          // row block 0..7 of the 128 rows
+            const int mi = blk & 3;
+            f32x4 v[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                v[ni] = (blk < 4) ? acc0[mi][ni] : acc1[mi][ni];
+                if constexpr ((EPI & EPI_BIAS) != 0) v[ni] += bias_v[ni];
+                if constexpr ((EPI & EPI_ROPE) != 0) {
+                    const f32x4 t = cs4[b][i][ni];   // c0 s0 c1 s1
+                    f32x4 q;
+                    q[0] = v[ni][0] * t[0] - v[ni][1] * t[1];
+                    q[1] = v[ni][1] * t[0] + v[ni][0] * t[1];
+                    q[2] = v[ni][2] * t[2] - v[ni][3] * t[3];
+                    q[3] = v[ni][3] * t[2] + v[ni][2] * t[3];
+                    v[ni] = q;
+                    if (q_tile) v[ni] *= p.q_scale;
+                }
+                if constexpr ((EPI & EPI_GELU_TANH) != 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[ni][e] = gelu_tanh_f(v[ni][e]);
+                }
+                if constexpr ((EPI & EPI_GELU_ERF) != 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[ni][e] = gelu_erf_f(v[ni][e]);
+                }
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x4 va = v[2 * pr], vb = v[2 * pr + 1];
+                if constexpr ((EPI & EPI_RES) != 0) {
+                    const u32x4 rw = res_wide[b][i][pr];
+                    const auto x0 = __builtin_amdgcn_permlane16_swap(rw[0], rw[2], false, false);
+                    const auto x1 = __builtin_amdgcn_permlane16_swap(rw[1], rw[3], false, false);
+                    va += f32x4{bf_lo(x0[0]), bf_hi(x0[0]), bf_lo(x1[0]), bf_hi(x1[0])};
+                    vb += f32x4{bf_lo(x0[1]), bf_hi(x0[1]), bf_lo(x1[1]), bf_hi(x1[1])};
+                }
+                const unsigned a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]);
+                const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                outv[i][pr] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+        }
+    };
+    auto store_batch = [&](const int b) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+                *reinterpret_cast<u32x4*>(cbase + (RB * b + i) * c_row16 + c_lane + 64 * pr) = outv[i][pr];
+    };
+    constexpr bool HAS_LOADS = (EPI & (EPI_RES | EPI_ROPE)) != 0;
+    if constexpr (HAS_LOADS) { load_batch(0); load_batch(1); }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        math_batch(b);
+        if constexpr (HAS_LOADS) { if (b + 2 < NB) load_batch(b + 2); }   // before this batch's stores (see above)
+        store_batch(b);
+    }
+}
+
+// Epilogue of the ping-pong kernel's 128x64 wave region: pipelined pair path when the whole region qualifies for the
+// lean path, else the two 64-row halves one after the other.
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_wave_pair(const EpiArgs& p, int mb, int nb, int M, int N, int lane,
+                                                   f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4]) {
+#ifndef COGS_EPI_NOPAIR   // (A/B builds only)
+    if constexpr (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0) {
+        bool fast = mb + 128 <= M && nb + 64 <= N && (N & 31) == 0 && (p.ldc & 7) == 0 &&
+                    (reinterpret_cast<unsigned long>(p.C) & 15) == 0;
+        if constexpr ((EPI & EPI_RES) != 0) fast = fast && (p.ldr & 7) == 0 && (reinterpret_cast<unsigned long>(p.R) & 15) == 0;
+        if constexpr ((EPI & EPI_ROPE) != 0) {
+            fast = fast && p.rope_sin == nullptr && p.head_dim >= 64 && (nb + 64 <= p.rope_cols || nb >= p.rope_cols) &&
+                   (nb + 64 <= p.q_cols || nb >= p.q_cols);
+            if (fast) {
+                if (nb < p.rope_cols) epilogue_pair_fast<EPI>(p, mb, nb, lane, acc0, acc1);
+                else epilogue_pair_fast<(EPI & ~EPI_ROPE)>(p, mb, nb, lane, acc0, acc1);
+                return;
+            }
+        } else {
+            if (fast) { epilogue_pair_fast<EPI>(p, mb, nb, lane, acc0, acc1); return; }
+        }
+    }
+#endif
+    epilogue_wave<T, EPI>(p, mb, nb, M, N, lane, acc0);
+    epilogue_wave<T, EPI>(p, mb + 64, nb, M, N, lane, acc1);
+}
+
 inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {
     if (g.act == COGS_ACT_SWIGLU && (g.bias || g.residual || g.out_f32)) return COGS_E_INVALID;
     if (g.rope_cos && (g.head_dim <= 0 || g.head_dim % 4 != 0 || g.rope_cols % g.head_dim != 0)) return COGS_E_INVALID;
