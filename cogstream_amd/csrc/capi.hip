@@ -6,6 +6,7 @@
 #include "kernels.h"
 
 #include <math.h>
+#include <stdint.h>
 #include <new>
 #include <string.h>
 #include <vector>
@@ -308,6 +309,7 @@ static size_t vit_carve(const cogs_vit_weights& w, int64_t N, int nframes, Carve
     *cu = (int32_t*)c.take((size_t)(nframes + 1) * sizeof(int32_t));
     *lo = (int32_t*)c.take((size_t)N * sizeof(int32_t));
     *hi = (int32_t*)c.take((size_t)N * sizeof(int32_t));
+    (void)c.take(28 * 1024);   // rotary position LUT (directly behind `hi`)
     return c.off;
 }
 
@@ -344,6 +346,18 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
     char* qkv = (char*)big;
     char* att = qkv + (size_t)N * 3 * H * es;
 
+    // rotary position LUT for the ping-pong QKV GEMM (bf16, block-diagonal): (cos, sin)[pos][freq], kept in LDS there
+    int maxpos = 0;
+    for (int v = 0; v < V; ++v) {
+        const int gh = (int)grid_sizes[3 * v + 1], gw = (int)grid_sizes[3 * v + 2];
+        maxpos = gh > maxpos ? gh : maxpos;
+        maxpos = gw > maxpos ? gw : maxpos;
+    }
+    float* lut = (float*)(hi + N);   // carved right behind `hi` (vit_carve)
+    lut = (float*)(((uintptr_t)lut + 255) & ~(uintptr_t)255);
+    const bool use_lut = dt == COGS_DT_BF16 && attn_mode == COGS_ATTN_BLOCK_DIAG && hd % 4 == 0 &&
+                         maxpos * (hd / 4) * 8 <= 27 * 1024;
+
     // cu_seqlens (:439-440), same-frame ranges for the eager-global mode, rotary tables (:405-434)
     h->h_cu.assign(1, 0);
     int max_seq = 0;
@@ -356,6 +370,11 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
             const int per = gh * gw;
             if (per > max_seq) max_seq = per;
             { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_vit_rope_table(st, rc, rs, (int)row, t, gh, gw, (int)merge_sizes[v], h->vit_inv_freq, h->vit_nfreq)); }
+            if (use_lut) {   // `lo` is free in block-diagonal mode: per-row positions; the LUT itself once (first video)
+                PROF(COGS_PROF_OTHER);
+                COGS_TRY(cogs_k_vit_rope_lut(st, lo, (int)row, t, gh, gw, (int)merge_sizes[v], v == 0 ? lut : nullptr, maxpos,
+                                             h->vit_inv_freq, h->vit_nfreq));
+            }
             for (int f = 0; f < t; ++f) {
                 if (need_rows)
                     for (int r = 0; r < per; ++r) { h->h_lo[row + r] = (int32_t)row; h->h_hi[row + r] = (int32_t)(row + per); }
@@ -392,6 +411,7 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
             g.bias = L.qkv_b; g.M = (int)N; g.N = 3 * H; g.K = H;
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = 2 * H; g.head_dim = hd;
             if (prescale_q) { g.q_scale = scale * 1.4426950408889634f; g.q_cols = H; }
+            if (use_lut) { g.rope_lut = lut; g.rope_rowpos = lo; g.rope_maxpos = maxpos; }
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         {

@@ -44,6 +44,7 @@ struct GemmArgs {
     const char* W; long ldw;   // bytes per row
     int M, N, K;
     int nbm, nbn;
+    const float* rope_lut; int rope_lut_bytes;   // EPI_ROPE_LUT: global LUT copied to LDS behind the ring at kernel start
     unsigned long long* trace;   // diagnostics (COGS_GEMM_TRACE): per-tile s_memtime stamps of WG 0, waves 0 and 4
     EpiArgs epi;
 };
@@ -443,6 +444,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
     u32x4 afr[4], wfr[4];
 
     if (st_t >= nb) return;
+    if constexpr ((EPI & EPI_ROPE_LUT) != 0) {
+        // rotary LUT -> LDS behind the ring (published by the prologue barrier below)
+        for (int i = tid * 16; i < p.rope_lut_bytes; i += 512 * 16)
+            *reinterpret_cast<u32x4*>(smem + RING3 * SLOT3 + i) = *reinterpret_cast<const u32x4*>(
+                reinterpret_cast<const char*>(p.rope_lut) + i);
+    }
     set_src(st_t);
     const int my_tiles = (nb - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
     const int total = my_tiles * KT;          // K-tiles this workgroup consumes
@@ -455,6 +462,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
         else if (pre == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if constexpr ((EPI & EPI_ROPE_LUT) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LUT writes landed
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
@@ -465,17 +473,27 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
     // conservative count. `epi_stores` is what the previous tile's epilogue left in flight.
     // (A 256x128 ping-pong variant for N = 1152 was measured 10-15 % slower than the ring kernel: 64x64 per
     // wave makes the L segment -- 8 reads + 3 DMA pieces -- too heavy for 16 MFMAs.)
-    constexpr bool WIDE_EPI = (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0;
-    int epi_stores = 0;
+    int epi_ops = 0;   // vector-memory instructions of the previous tile's epilogue when known exactly, else 0
+    constexpr int PAIR_OK = (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0;
+    constexpr int OPS_A = epi_pair_vmem_ops<EPI>();                                   // rotary / plain tile
+    constexpr int OPS_B = epi_pair_vmem_ops<(EPI & ~(EPI_ROPE | EPI_ROPE_LUT))>();    // tile right of rope_cols
     auto wait_next_ktile = [&](int ahead, int kt) {
         // K-tile g+1 has landed when at most the pieces of the K-tiles staged after it are outstanding:
-        // min(ahead, DIST3) - 1 K-tiles of 4 pieces, plus the 16 epilogue stores while they are still newer than it
-        const bool relaxed = epi_stores == 16 && kt < DIST3 - 1;
+        // min(ahead, DIST3) - 1 K-tiles of 4 pieces -- plus, for the first DIST3-1 K-tiles of a tile, every vector-
+        // memory instruction of the previous tile's epilogue (stores AND its bias / residual / rotary loads: one
+        // in-order queue), all of which were issued after those pieces. (The count must be an immediate; the
+        // epilogue reports which of its two compile-time counts applies. A generic switch over the count costs
+        // ~200 scalar cycles per K-tile -- measured slower than not relaxing at all.)
+        if (PAIR_OK && epi_ops != 0 && kt < DIST3 - 1 && ahead >= DIST3) {
+            if (epi_ops == OPS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DIST3 - 1) + OPS_A) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DIST3 - 1) + OPS_B) : "memory");
+            return;
+        }
         const int newer = (ahead < DIST3 ? ahead : DIST3) - 1;
-        if (newer >= 3) { if (relaxed) asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-        else if (newer == 2) { if (relaxed) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else if (newer == 1) { if (relaxed) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else { if (relaxed) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (newer >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     int slot = 0;
@@ -596,9 +614,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
         // epilogue of this tile; it runs inside this group's next L interval, i.e. beside the other group's C
         stamp();
         stamp();
-        epilogue_wave_pair<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0], acc[1]);
+        const int ops = epilogue_wave_pair<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0], acc[1]);
         stamp();
-        epi_stores = (WIDE_EPI && (p.N & 31) == 0 && m0 + BM3 <= p.M && n0 + BN3 <= p.N) ? 16 : 0;
+        epi_ops = ops > 0 ? ops : 0;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
 }
@@ -640,7 +658,7 @@ void launch_big(hipStream_t st, const GemmArgs& p, int grid) {
 }
 template <int EPI>
 void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
-    const size_t lds = RING3 * SLOT3;
+    const size_t lds = RING3 * SLOT3 + ((EPI & EPI_ROPE_LUT) ? 28 * 1024 : 0);   // ring (+ rotary LUT, <= 28 KiB)
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -685,6 +703,7 @@ void dispatch_pp(hipStream_t st, const GemmArgs& p, int grid, int mask) {
         COGS_PP_CASE(EPI_RES)
         COGS_PP_CASE(EPI_BIAS | EPI_RES)
         COGS_PP_CASE(EPI_BIAS | EPI_ROPE)
+        COGS_PP_CASE(EPI_BIAS | EPI_ROPE | EPI_ROPE_LUT)
         COGS_PP_CASE(EPI_BIAS | EPI_GELU_TANH)
         COGS_PP_CASE(EPI_BIAS | EPI_GELU_ERF)
         COGS_PP_CASE(EPI_SWIGLU)
@@ -725,7 +744,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     if (g.M == 1) { ++g_gemm_launches; return cogs_k_gemv(st, g); }
     if (g.rms_gamma) return COGS_E_UNSUPPORTED;   // fused RMSNorm exists for the single-token GEMV only
     GemmArgs p;
-    p.trace = nullptr;
+    p.trace = nullptr; p.rope_lut = nullptr; p.rope_lut_bytes = 0;
     const int rc = cogs_fill_epi(g, &p.epi);
     if (rc != COGS_OK) return rc;
     p.A = (const char*)g.A; p.lda = g.lda * es;
@@ -741,6 +760,17 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         p.nbm = (g.M + BM3 - 1) / BM3;
         p.nbn = (g.N + BN3 - 1) / BN3;
         static const bool env_nostore = getenv("COGS_GEMM_NOSTORE") != nullptr;
+        static const bool env_nolut = getenv("COGS_GEMM_NOLUT") != nullptr;
+        int pp_mask = cogs_epi_mask(g);
+        p.rope_lut = nullptr; p.rope_lut_bytes = 0;
+        if (pp_mask == (EPI_BIAS | EPI_ROPE) && g.rope_lut && g.rope_rowpos && !g.rope_sin && !env_nolut) {
+            const int lut_bytes = g.rope_maxpos * (g.head_dim / 4) * 8;
+            if (lut_bytes > 0 && lut_bytes <= 28 * 1024 && g.rope_maxpos < 65536) {
+                pp_mask |= EPI_ROPE_LUT;
+                p.rope_lut = g.rope_lut; p.rope_lut_bytes = lut_bytes;
+                p.epi.rope_lut_lds = RING3 * SLOT3;
+            }
+        }
         // Round-aligned split. The persistent kernel walks nbm*nbn tiles with 256 workgroups; when the last round
         // is mostly empty (N = 1152 at cfg2: 1155 tiles = 4.5 rounds, half the CUs idle for a whole tile time) the
         // leading row blocks that make up WHOLE rounds stay here and the remaining rows go to the 256x128 kernel,
@@ -759,19 +789,20 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
                 b.A = (const char*)g.A + (size_t)rows_main * g.lda * es;
                 b.C = (char*)g.C + (size_t)rows_main * g.ldc * (g.out_f32 ? 4 : es);
                 if (g.residual) b.residual = (const char*)g.residual + (size_t)rows_main * g.ldr * es;
+                if (g.rope_rowpos) b.rope_rowpos = g.rope_rowpos + rows_main;
                 if (g.rope_cos) {
                     const size_t per_row = (size_t)(g.head_dim / 2) * (g.rope_sin ? 1 : 2);
                     b.rope_cos = g.rope_cos + (size_t)rows_main * per_row;
                     if (g.rope_sin) b.rope_sin = g.rope_sin + (size_t)rows_main * per_row;
                 }
                 p.M = rows_main; p.nbm = mb_main;
-                dispatch_pp(st, p, p.nbm * p.nbn, cogs_epi_mask(g));
+                dispatch_pp(st, p, p.nbm * p.nbn, pp_mask);
                 const int rc2 = COGS_LAUNCH_CHECK();
                 if (rc2 != COGS_OK) return rc2;
                 return cogs_k_gemm(st, b);
             }
         }
-        dispatch_pp(st, p, nb, env_nostore ? EPI_NOSTORE : cogs_epi_mask(g));
+        dispatch_pp(st, p, nb, env_nostore ? EPI_NOSTORE : pp_mask);
         return COGS_LAUNCH_CHECK();
     }
     const bool big = g.M >= 512 && !g.force_small_tile && !env_small;

@@ -27,6 +27,7 @@
 #define EPI_SWIGLU 32
 #define EPI_F32OUT 64
 #define EPI_GENERIC 128   // decide everything at run time (rare combinations)
+#define EPI_ROPE_LUT 512  // with EPI_ROPE, ping-pong kernel only: rotary factors from the LDS-resident position LUT
 #define EPI_NOSTORE 256   // diagnostics only (COGS_GEMM_NOSTORE): accumulators kept live, nothing written
 
 struct EpiArgs {
@@ -40,6 +41,9 @@ struct EpiArgs {
     int rope_pairs;
     int rope_cols;
     int head_dim;
+    const int* rope_rowpos;     // EPI_ROPE_LUT: [M] h | w << 16
+    int rope_lut_lds;           //   byte offset of the LUT inside the kernel's dynamic LDS
+    int rope_maxpos;            //   positions in the LUT (LUT row = rope_pairs/2 frequencies x (cos, sin))
     float q_scale;              // != 1: columns < q_cols are multiplied by it after bias/rope, before the (single) rounding
     int q_cols;                 //   (the attention kernels then take Q pre-scaled by softmax_scale*log2(e))
 };
@@ -435,82 +439,107 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
             cs_lane[ni] = (unsigned)(r * p.rope_pairs * 8 + c * 4);
         }
     }
-    // batch = RB row blocks of 16 rows: 2 (32 rows, 4 batches) normally, 1 (8 batches) with rotary loads, whose
-    // 16 registers per row block would otherwise push the kernel into spills
-    constexpr int RB = (EPI & EPI_ROPE) != 0 ? 1 : 2;
-    constexpr int NB = 8 / RB;
-    u32x4 res_wide[NB][RB][2];   // [batch][row block of the batch][tile pair]
-    f32x4 cs4[NB][RB][4];
-    auto load_batch = [&](const int b) {
-        if constexpr ((EPI & EPI_RES) != 0) {
+    // EPI_ROPE_LUT: per-lane LUT addressing (fixed for the tile) and the row positions of the lane's 8 row blocks
+    extern __shared__ __attribute__((aligned(16))) char epi_smem[];
+    const char* lut_base = nullptr;
+    int lut_off[4] = {0, 0, 0, 0}, lut_row = 0, rowpos_v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool lut_w[4] = {false, false, false, false};
+    if constexpr ((EPI & EPI_ROPE_LUT) != 0) {
+        const int nf = p.rope_pairs >> 1;               // frequencies per axis
+        lut_base = epi_smem + p.rope_lut_lds;
+        lut_row = nf * 8;
+        const int nbmod = nb % p.head_dim;
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr)
-                    res_wide[b][i][pr] = *reinterpret_cast<const u32x4*>(rbase + (RB * b + i) * r_row16 + r_lane + 64 * pr);
+        for (int ni = 0; ni < 4; ++ni) {
+            int c = nbmod + 16 * ni + 4 * g4;
+            c -= c >= p.head_dim ? p.head_dim : 0;
+            const int pi = c >> 1;                       // even pair index inside the head
+            lut_w[ni] = pi >= nf;
+            lut_off[ni] = (pi - (lut_w[ni] ? nf : 0)) * 8;
         }
-        if constexpr ((EPI & EPI_ROPE) != 0) {
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+        for (int blk = 0; blk < 8; ++blk) rowpos_v[blk] = p.rope_rowpos[mb + 16 * blk + r];
+    }
+    // The region is 16 units of (16-row block blk, 32-column tile pair pr); a unit ends in ONE 16-byte store per lane.
+    // A batch is UPB consecutive units: 4 (two row blocks) normally, 1 with rotary loads -- two batches are in flight
+    // and a rotary unit already holds 8 registers of (cos, sin), so finer batches keep the kernel out of spills.
+    constexpr int UPB = (EPI & EPI_ROPE) != 0 ? 1 : 4;
+    constexpr int NB = 16 / UPB;
+    u32x4 res_wide[NB][UPB];
+    f32x4 cs4[NB][UPB][2];
+    auto load_batch = [&](const int b) {
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    cs4[b][i][ni] = *reinterpret_cast<const f32x4*>(csbase + (RB * b + i) * cs_row16 + cs_lane[ni]);
+        for (int j = 0; j < UPB; ++j) {
+            const int u = UPB * b + j, blk = u >> 1, pr = u & 1;
+            if constexpr ((EPI & EPI_RES) != 0)
+                res_wide[b][j] = *reinterpret_cast<const u32x4*>(rbase + blk * r_row16 + r_lane + 64 * pr);
+            if constexpr ((EPI & EPI_ROPE) != 0) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int ni = 2 * pr + h2;
+                    if constexpr ((EPI & EPI_ROPE_LUT) != 0) {
+                        // LDS LUT: row = position (h for the first half of the head's pairs, w for the second)
+                        const int rp = rowpos_v[blk];
+                        const int pos = lut_w[ni] ? (rp >> 16) : (rp & 0xffff);
+                        cs4[b][j][h2] = *reinterpret_cast<const f32x4*>(lut_base + lut_off[ni] + pos * lut_row);
+                    } else {
+                        cs4[b][j][h2] = *reinterpret_cast<const f32x4*>(csbase + blk * cs_row16 + cs_lane[ni]);
+                    }
+                }
+            }
         }
     };
-    u32x4 outv[RB][2];
+    u32x4 outv[UPB];
     auto math_batch = [&](const int b) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int blk = RB * b + i;          // row block 0..7 of the 128 rows
-            const int mi = blk & 3;
-            f32x4 v[4];
+        for (int j = 0; j < UPB; ++j) {
+            const int u = UPB * b + j, blk = u >> 1, pr = u & 1, mi = blk & 3;
+            f32x4 v[2];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                v[ni] = (blk < 4) ? acc0[mi][ni] : acc1[mi][ni];
-                if constexpr ((EPI & EPI_BIAS) != 0) v[ni] += bias_v[ni];
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int ni = 2 * pr + h2;
+                v[h2] = (blk < 4) ? acc0[mi][ni] : acc1[mi][ni];
+                if constexpr ((EPI & EPI_BIAS) != 0) v[h2] += bias_v[ni];
                 if constexpr ((EPI & EPI_ROPE) != 0) {
-                    const f32x4 t = cs4[b][i][ni];   // c0 s0 c1 s1
+                    const f32x4 t = cs4[b][j][h2];   // c0 s0 c1 s1
                     f32x4 q;
-                    q[0] = v[ni][0] * t[0] - v[ni][1] * t[1];
-                    q[1] = v[ni][1] * t[0] + v[ni][0] * t[1];
-                    q[2] = v[ni][2] * t[2] - v[ni][3] * t[3];
-                    q[3] = v[ni][3] * t[2] + v[ni][2] * t[3];
-                    v[ni] = q;
-                    if (q_tile) v[ni] *= p.q_scale;
+                    q[0] = v[h2][0] * t[0] - v[h2][1] * t[1];
+                    q[1] = v[h2][1] * t[0] + v[h2][0] * t[1];
+                    q[2] = v[h2][2] * t[2] - v[h2][3] * t[3];
+                    q[3] = v[h2][3] * t[2] + v[h2][2] * t[3];
+                    v[h2] = q;
+                    if (q_tile) v[h2] *= p.q_scale;
                 }
                 if constexpr ((EPI & EPI_GELU_TANH) != 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[ni][e] = gelu_tanh_f(v[ni][e]);
+                    for (int e = 0; e < 4; ++e) v[h2][e] = gelu_tanh_f(v[h2][e]);
                 }
                 if constexpr ((EPI & EPI_GELU_ERF) != 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[ni][e] = gelu_erf_f(v[ni][e]);
+                    for (int e = 0; e < 4; ++e) v[h2][e] = gelu_erf_f(v[h2][e]);
                 }
             }
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                f32x4 va = v[2 * pr], vb = v[2 * pr + 1];
-                if constexpr ((EPI & EPI_RES) != 0) {
-                    const u32x4 rw = res_wide[b][i][pr];
-                    const auto x0 = __builtin_amdgcn_permlane16_swap(rw[0], rw[2], false, false);
-                    const auto x1 = __builtin_amdgcn_permlane16_swap(rw[1], rw[3], false, false);
-                    va += f32x4{bf_lo(x0[0]), bf_hi(x0[0]), bf_lo(x1[0]), bf_hi(x1[0])};
-                    vb += f32x4{bf_lo(x0[1]), bf_hi(x0[1]), bf_lo(x1[1]), bf_hi(x1[1])};
-                }
-                const unsigned a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]);
-                const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
-                const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                outv[i][pr] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            f32x4 va = v[0], vb = v[1];
+            if constexpr ((EPI & EPI_RES) != 0) {
+                const u32x4 rw = res_wide[b][j];
+                const auto x0 = __builtin_amdgcn_permlane16_swap(rw[0], rw[2], false, false);
+                const auto x1 = __builtin_amdgcn_permlane16_swap(rw[1], rw[3], false, false);
+                va += f32x4{bf_lo(x0[0]), bf_hi(x0[0]), bf_lo(x1[0]), bf_hi(x1[0])};
+                vb += f32x4{bf_lo(x0[1]), bf_hi(x0[1]), bf_lo(x1[1]), bf_hi(x1[1])};
             }
+            const unsigned a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]);
+            const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
+            const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+            outv[j] = u32x4{s0[0], s1[0], s0[1], s1[1]};
         }
     };
     auto store_batch = [&](const int b) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr)
-                *reinterpret_cast<u32x4*>(cbase + (RB * b + i) * c_row16 + c_lane + 64 * pr) = outv[i][pr];
+        for (int j = 0; j < UPB; ++j) {
+            const int u = UPB * b + j, blk = u >> 1, pr = u & 1;
+            *reinterpret_cast<u32x4*>(cbase + blk * c_row16 + c_lane + 64 * pr) = outv[j];
+        }
     };
     constexpr bool HAS_LOADS = (EPI & (EPI_RES | EPI_ROPE)) != 0;
     if constexpr (HAS_LOADS) { load_batch(0); load_batch(1); }
@@ -522,11 +551,17 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
     }
 }
 
-// Epilogue of the ping-pong kernel's 128x64 wave region: pipelined pair path when the whole region qualifies for the
-// lean path, else the two 64-row halves one after the other.
+// vector-memory instructions (loads + stores; they share the in-order vmcnt queue) one epilogue_pair_fast<EPI> issues
+template <int EPI>
+constexpr int epi_pair_vmem_ops() {
+    return 16 + ((EPI & EPI_BIAS) ? 4 : 0) + ((EPI & EPI_RES) ? 16 : 0) +
+           ((EPI & EPI_ROPE) ? ((EPI & EPI_ROPE_LUT) ? 8 : 32) : 0);
+}
+
+// Returns the number of vector-memory instructions issued when that is known exactly (pipelined path), else -1.
 template <typename T, int EPI>
-__device__ __forceinline__ void epilogue_wave_pair(const EpiArgs& p, int mb, int nb, int M, int N, int lane,
-                                                   f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4]) {
+__device__ __forceinline__ int epilogue_wave_pair(const EpiArgs& p, int mb, int nb, int M, int N, int lane,
+                                                  f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4]) {
 #ifndef COGS_EPI_NOPAIR   // (A/B builds only)
     if constexpr (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0) {
         bool fast = mb + 128 <= M && nb + 64 <= N && (N & 31) == 0 && (p.ldc & 7) == 0 &&
@@ -536,17 +571,18 @@ __device__ __forceinline__ void epilogue_wave_pair(const EpiArgs& p, int mb, int
             fast = fast && p.rope_sin == nullptr && p.head_dim >= 64 && (nb + 64 <= p.rope_cols || nb >= p.rope_cols) &&
                    (nb + 64 <= p.q_cols || nb >= p.q_cols);
             if (fast) {
-                if (nb < p.rope_cols) epilogue_pair_fast<EPI>(p, mb, nb, lane, acc0, acc1);
-                else epilogue_pair_fast<(EPI & ~EPI_ROPE)>(p, mb, nb, lane, acc0, acc1);
-                return;
+                if (nb < p.rope_cols) { epilogue_pair_fast<EPI>(p, mb, nb, lane, acc0, acc1); return epi_pair_vmem_ops<EPI>(); }
+                epilogue_pair_fast<(EPI & ~(EPI_ROPE | EPI_ROPE_LUT))>(p, mb, nb, lane, acc0, acc1);
+                return epi_pair_vmem_ops<(EPI & ~(EPI_ROPE | EPI_ROPE_LUT))>();
             }
         } else {
-            if (fast) { epilogue_pair_fast<EPI>(p, mb, nb, lane, acc0, acc1); return; }
+            if (fast) { epilogue_pair_fast<EPI>(p, mb, nb, lane, acc0, acc1); return epi_pair_vmem_ops<EPI>(); }
         }
     }
 #endif
-    epilogue_wave<T, EPI>(p, mb, nb, M, N, lane, acc0);
-    epilogue_wave<T, EPI>(p, mb + 64, nb, M, N, lane, acc1);
+    epilogue_wave<T, (EPI & ~EPI_ROPE_LUT)>(p, mb, nb, M, N, lane, acc0);          // boundary tiles: per-row table
+    epilogue_wave<T, (EPI & ~EPI_ROPE_LUT)>(p, mb + 64, nb, M, N, lane, acc1);
+    return -1;
 }
 
 inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {
@@ -561,6 +597,7 @@ inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {
     e->rope_pairs = g.head_dim / 2; e->rope_cols = g.rope_cols;
     e->head_dim = g.head_dim > 0 ? g.head_dim : 4;
     e->q_scale = g.q_scale; e->q_cols = g.q_scale != 1.f ? g.q_cols : 0;
+    e->rope_rowpos = g.rope_rowpos; e->rope_lut_lds = 0; e->rope_maxpos = g.rope_maxpos;
     return COGS_OK;
 }
 

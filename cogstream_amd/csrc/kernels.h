@@ -33,6 +33,10 @@ struct CogsGemm {
     void* kv_k = nullptr; void* kv_v = nullptr; int kv_col0 = 0; int kv_dim = 0;
     // rope epilogues only: columns [0, q_cols) (the Q heads) are multiplied by q_scale before rounding
     float q_scale = 1.f; int q_cols = 0;
+    // optional 2-D rotary LUT (ViT): rope_lut [maxpos][head_dim/4][2] fp32 = (cos, sin) of pos*inv_freq[f], rope_rowpos
+    // [M] = h | w << 16. The ping-pong kernel keeps the LUT in LDS and reads the factors from there (first half of a
+    // head's pairs rotates with h, second half with w); rope_cos must still be the matching per-row table.
+    const float* rope_lut = nullptr; const int* rope_rowpos = nullptr; int rope_maxpos = 0;
 };
 int cogs_k_gemm(hipStream_t st, const CogsGemm& g);
 
@@ -74,6 +78,8 @@ int cogs_k_pack_rows(hipStream_t st, int in_dtype, int out_dtype, const void* in
                      long ld_out, int rows, int cols_in, int cols_out);
 int cogs_k_vit_rope_table(hipStream_t st, float* cos_t, float* sin_t, int row0, int t, int gh, int gw, int ms,
                           const float* inv_freq, int n_freq);
+int cogs_k_vit_rope_lut(hipStream_t st, int* rowpos, int row0, int t, int gh, int gw, int ms, float* lut, int maxpos,
+                        const float* inv_freq, int n_freq);
 int cogs_k_llm_rope_table(hipStream_t st, float* cos_t, float* sin_t, const int* pos, int pos0, int rows,
                           const float* inv_freq, int n_freq);
 

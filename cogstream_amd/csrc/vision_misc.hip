@@ -52,6 +52,32 @@ __global__ __launch_bounds__(256) void vit_rope_kernel(float* cos_t, float* sin_
     }
 }
 
+// per-row (h | w << 16) position of the 2-D rotary embedding, same row order as vit_rope_kernel
+__global__ __launch_bounds__(256) void vit_rowpos_kernel(int* rowpos, int row0, int t, int gh, int gw, int ms) {
+    const int per_frame = gh * gw;
+    const long total = (long)t * per_frame;
+    const int wpr = gw / ms;
+    for (long row = (long)blockIdx.x * blockDim.x + threadIdx.x; row < total; row += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(row % per_frame);
+        const int win = r / (ms * ms), in = r % (ms * ms);
+        const int hpos = (win / wpr) * ms + in / ms;
+        const int wpos = (win % wpr) * ms + in % ms;
+        rowpos[row0 + row] = hpos | (wpos << 16);
+    }
+}
+
+// (cos, sin) of pos * inv_freq[f] for pos < maxpos: lut[pos][f][2]; the SAME expression as vit_rope_kernel, so a
+// GEMM tile that reads the LUT and one that reads the per-row table see bit-identical factors
+__global__ __launch_bounds__(256) void vit_rope_lut_kernel(float* lut, int maxpos, const float* inv_freq, int nf) {
+    const int total = maxpos * nf;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int f = i % nf, pos = i / nf;
+        const float ang = (float)pos * inv_freq[f];
+        lut[2 * i] = cosf(ang);
+        lut[2 * i + 1] = sinf(ang);
+    }
+}
+
 __global__ __launch_bounds__(256) void llm_rope_kernel(float* cos_t, float* sin_t, const int* pos, int pos0, int rows,
                                                        const float* inv_freq, int nf) {
     const long total = (long)rows * nf;
@@ -100,6 +126,16 @@ int cogs_k_vit_rope_table(hipStream_t st, float* cos_t, float* sin_t, int row0, 
     const long total = (long)t * gh * gw * 2 * n_freq;
     hipLaunchKernelGGL(vit_rope_kernel, dim3(grid_for(total)), dim3(256), 0, st, cos_t, sin_t, row0, t, gh, gw, ms,
                        inv_freq, n_freq);
+    return COGS_LAUNCH_CHECK();
+}
+
+int cogs_k_vit_rope_lut(hipStream_t st, int* rowpos, int row0, int t, int gh, int gw, int ms, float* lut, int maxpos,
+                        const float* inv_freq, int n_freq) {
+    if (t <= 0 || gh <= 0 || gw <= 0 || ms <= 0 || gh % ms || gw % ms) return COGS_E_INVALID;
+    hipLaunchKernelGGL(vit_rowpos_kernel, dim3(grid_for((long)t * gh * gw)), dim3(256), 0, st, rowpos, row0, t, gh, gw, ms);
+    if (lut)
+        hipLaunchKernelGGL(vit_rope_lut_kernel, dim3(grid_for((long)maxpos * n_freq)), dim3(256), 0, st, lut, maxpos, inv_freq,
+                           n_freq);
     return COGS_LAUNCH_CHECK();
 }
 

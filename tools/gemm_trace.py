@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "vit"
 M = 59136 if which == "vit" else 15396
 bf = torch.bfloat16
-shapes = ([("qkv plain", 3456, 1152, {}), ("fc1 plain", 4352, 1152, {}),
+shapes = ([("qkv plain", 3456, 1152, {}), ("qkv bias+rope", 3456, 1152, dict(bias=True, rope=True)), ("fc1 plain", 4352, 1152, {}),
            ("fc1 gelu", 4352, 1152, dict(bias=True, act=L.ACT_GELU_TANH)), ("fc2 res", 1152, 4352, dict(res=True))]
           if which == "vit" else
           [("gate/up swiglu", 37888, 3584, dict(act=L.ACT_SWIGLU)), ("gate/up plain", 37888, 3584, {}),
@@ -29,6 +29,8 @@ for name, N, K, kw in shapes:
         args["residual"] = torch.zeros(M, N, device=dev, dtype=bf)
     if kw.get("act"):
         args["act"] = kw["act"]
+    if kw.get("rope"):
+        args.update(rope_cos=torch.rand(M, 36, 2, device=dev), rope_sin=None, rope_cols=2304, head_dim=72)
     os.environ["COGS_GEMM_NOSPLIT"] = "1"
     print("==", name, file=sys.stderr)
     for _ in range(2):
