@@ -45,6 +45,9 @@ class GemmDesc(C.Structure):
         ("rope_sin", c_void_p),
         ("rope_cols", c_int),
         ("head_dim", c_int),
+        ("rope_lut", c_void_p),
+        ("rope_rowpos", c_void_p),
+        ("rope_maxpos", c_int),
     ]
 
 

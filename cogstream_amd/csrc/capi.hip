@@ -92,6 +92,7 @@ CogsGemm to_gemm(const cogs_gemm_desc* d) {
     g.bias = d->bias; g.residual = d->residual; g.ldr = d->ldr;
     g.M = d->M; g.N = d->N; g.K = d->K; g.act = d->act; g.out_f32 = d->out_f32;
     g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.rope_cols = d->rope_cols; g.head_dim = d->head_dim;
+    g.rope_lut = d->rope_lut; g.rope_rowpos = d->rope_rowpos; g.rope_maxpos = d->rope_maxpos;
     return g;
 }
 

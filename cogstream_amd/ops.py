@@ -36,7 +36,7 @@ def k_slab(dtype) -> int:
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
          residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False,
          rope_cos: Optional[torch.Tensor] = None, rope_sin: Optional[torch.Tensor] = None, rope_cols: int = 0,
-         head_dim: int = 0) -> torch.Tensor:
+         head_dim: int = 0, rope_lut: Optional[torch.Tensor] = None, rope_rowpos: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)  (see cogs_gemm in include/cogs.h)"""
     _need_cuda(a, w, bias, residual, out)
     M, K = a.shape
@@ -55,6 +55,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     d.M, d.N, d.K = M, N, K
     d.act, d.out_f32 = act, int(out_f32)
     d.rope_cos, d.rope_sin, d.rope_cols, d.head_dim = ptr(rope_cos), ptr(rope_sin), rope_cols, head_dim
+    d.rope_lut, d.rope_rowpos = ptr(rope_lut), ptr(rope_rowpos)
+    d.rope_maxpos = int(rope_lut.shape[0]) if rope_lut is not None else 0
     check(L.lib.cogs_gemm(current_stream(), C.byref(d)), "cogs_gemm")
     return out
 

@@ -95,6 +95,13 @@ typedef struct {
     const float* rope_sin;
     int rope_cols;
     int head_dim;
+    /* optional 2-D rotary position LUT (ViT): rope_lut [rope_maxpos][head_dim/4][2] fp32 = (cos, sin)(pos * inv_freq[f]),
+     * rope_rowpos [M] int32 = h | w << 16; the first half of a head's pairs rotates with h, the second with w. Large
+     * bf16 GEMMs then read the factors from an LDS copy of the LUT; rope_cos must still hold the matching interleaved
+     * per-row table (rope_sin NULL) for the tiles that do not take that path. */
+    const float* rope_lut;
+    const int32_t* rope_rowpos;
+    int rope_maxpos;
 } cogs_gemm_desc;
 cogs_status cogs_gemm(cogs_stream stream, const cogs_gemm_desc* d);
 

@@ -118,6 +118,46 @@ def test_gemm_rope_epilogue(dev, M, heads, interleaved):
     assert rel_err(out.float().view(M, 3 * heads, hd), refp) < 1.2e-2
 
 
+def test_gemm_rope_position_lut_equals_row_table(dev):
+    """the ping-pong GEMM's LDS position LUT (2-D rotary: first half of a head's pairs uses the row's h, second half
+    its w) must give bit-identical outputs to the per-row (cos, sin) table built from the same angles -- and both
+    must match the plain reference"""
+    ops = _ops()
+    torch.manual_seed(17)
+    hd, heads, K, M = 72, 7, 128, 1500            # N = 1512: ping-pong kernel; ragged last row block; rope straddle
+    nf, maxpos = hd // 4, 45
+    N = 3 * heads * hd
+    x = torch.randn(M, K).bfloat16()
+    w = (torch.randn(N, K) / 11).bfloat16()
+    b = torch.randn(N).bfloat16()
+    hpos, wpos = torch.randint(0, 23, (M,)), torch.randint(0, maxpos, (M,))
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(nf, dtype=torch.float32) / nf))
+    lut_ang = torch.arange(maxpos, dtype=torch.float32)[:, None] * inv_freq[None, :]            # [maxpos, nf]
+    lut = torch.stack([lut_ang.cos(), lut_ang.sin()], -1).contiguous()                          # [maxpos, nf, 2]
+    ang = torch.cat([hpos[:, None].float() * inv_freq[None, :], wpos[:, None].float() * inv_freq[None, :]], 1)   # [M, hd/2]
+    table = torch.cat([lut[hpos], lut[wpos]], 1).contiguous()                                   # [M, hd/2, 2] same values
+    assert torch.equal(table[..., 0], torch.cat([lut_ang[hpos], lut_ang[wpos]], 1).cos())
+    rowpos = (hpos | (wpos << 16)).to(torch.int32)
+    perm = torch.arange(hd).view(2, hd // 2).t().reshape(-1)
+    wp = w.view(3 * heads, hd, K).clone()
+    bp = b.view(3 * heads, hd).clone()
+    wp[:2 * heads] = wp[:2 * heads][:, perm]
+    bp[:2 * heads] = bp[:2 * heads][:, perm]
+    args = dict(rope_cos=table.to(dev), rope_sin=None, rope_cols=2 * heads * hd, head_dim=hd)
+    xa, wa, ba = x.to(dev), wp.reshape(N, K).contiguous().to(dev), bp.reshape(N).contiguous().to(dev)
+    out_tab = ops.gemm(xa, wa, ba, **args)
+    out_lut = ops.gemm(xa, wa, ba, rope_lut=lut.to(dev), rope_rowpos=rowpos.to(dev), **args)
+    assert torch.equal(out_lut, out_tab)
+    y = (x.float() @ w.float().t() + b.float()).view(M, 3 * heads, hd)
+    cos = torch.cat([ang.cos(), ang.cos()], -1)[:, None, :]
+    sin = torch.cat([ang.sin(), ang.sin()], -1)[:, None, :]
+    rot = torch.cat([-y[..., hd // 2:], y[..., :hd // 2]], -1)
+    ref = y.clone()
+    ref[:, :2 * heads] = (y * cos + rot * sin)[:, :2 * heads]
+    ref[:, :2 * heads] = ref[:, :2 * heads][:, :, perm]
+    assert rel_err(out_lut.float().view(M, 3 * heads, hd), ref) < 1.2e-2
+
+
 def _attn_ref(q, k, v, hq, hkv, hd, cu=None, causal=False, q_pos0=0, row_lo=None, row_hi=None, bias=0.0, scale=None):
     Lq, Lk = q.shape[0], k.shape[0]
     q = q.float().view(Lq, hq, hd).transpose(0, 1)
