@@ -102,21 +102,34 @@ template <> __device__ __forceinline__ void st8_f<float>(float* p, const float (
     *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
-// 64-lane butterfly reductions (fixed order -> deterministic)
-__device__ __forceinline__ float wave_sum(float v) {
+// 64-lane butterfly reductions (fixed order -> deterministic). The xor-32 and xor-16 exchanges go through
+// v_permlane32_swap / v_permlane16_swap (both operands = v: afterwards the two results hold "mine" and "partner's" in
+// some order, and the operation is commutative) instead of the ds_bpermute round trips __shfl_xor compiles to;
+// xor 8..1 stay __shfl_xor (DPP). Same values, bit for bit.
+template <typename F>
+__device__ __forceinline__ float wave_butterfly(float v, F op) {
+    {
+        const unsigned b = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+        v = op(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    }
+    {
+        const unsigned b = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+        v = op(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 8; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o, 64));
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    return wave_butterfly(v, [](float a, float b) { return a + b; });
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    return wave_butterfly(v, [](float a, float b) { return fmaxf(a, b); });
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    return wave_butterfly(v, [](float a, float b) { return fminf(a, b); });
 }
 
 // activations (fp32)
