@@ -133,3 +133,16 @@ def test_result_json_layout(tmp_path):
     assert path.endswith("clip_007.json") and d == {"video_name": "clip_007", "Data": [recs]}
     text = open(path, encoding="utf-8").read()
     assert "\\u00e9" not in text and "\u00e9" in text               # ensure_ascii=False like the reference
+
+
+def test_cfg4_history_fixture_and_retrieval_prompt():
+    """the committed cfg4 session strings drive the retrieval prompt builder without surprises"""
+    import json
+    from cogstream_amd.qaselect import format_example
+    turns = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cfg4_history.json")))["turns"]
+    assert len(turns) == 8 and all(t["question"] and t["answer"] for t in turns)
+    prompt = format_example({"current_Q": turns[-1]["question"], "hist_Qs": [t["question"] for t in turns[:-1]],
+                             "hist_As": [t["answer"] for t in turns[:-1]]})
+    for i, t in enumerate(turns[:-1]):
+        assert t["question"] in prompt and t["answer"] in prompt
+    assert turns[-1]["question"] in prompt

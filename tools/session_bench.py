@@ -32,10 +32,12 @@ proj = Projector(random_proj_state(1152, 3584, 1, dev, bf), dtype=bf, device=dev
 eng = Qwen2Engine(random_llm_state(lcfg, 2, dev, bf), lcfg, dtype=bf, device=dev)
 tok = ToyTokenizer()
 procr = pr.CogStreamProcessor(tok, device=dev)
+import json  # noqa: E402
+hist = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg4_history.json")))["turns"]
 segs = []
 for i in range(turns):
     fr, ts = pr.synthetic_clip(fps_seg, kind="drift", clip_idx=i)
-    segs.append((fr, [t + fps_seg * i for t in ts], f"What happens in part {i}?"))
+    segs.append((fr, [t + fps_seg * i for t in ts], hist[i % len(hist)]["question"]))
 
 for cached in (False, True):
     model = CogReasoner(enc, proj, eng, lcfg, generation_config=dict(do_sample=False, eos_token_id=[-1], repetition_penalty=1.05))
