@@ -267,7 +267,7 @@ def main() -> None:
         ncpu = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         torch.set_num_threads(ncpu)
         st = rvs(vcfg, seed=0, device="cpu", dtype=torch.float32)
-        nfr = 2
+        nfr = 8   # ~10-15 s of CPU work on 16 cores (bounded sample)
         px = pix_all[:nfr * per_frame].float()
         g = torch.tensor([[nfr, gh, gw]])
         with torch.no_grad():
