@@ -68,7 +68,8 @@ cogs_status cogs_destroy(cogs_handle h);
 #define COGS_PROF_OTHER 3
 #define COGS_PROF_CLASSES 4
 cogs_status cogs_profile_begin(cogs_handle h);
-/* synchronises `stream`; ms_per_class / launches_per_class: host arrays [COGS_PROF_CLASSES] */
+/* synchronises `stream`; ms_per_class / launches_per_class: host arrays [COGS_PROF_CLASSES]; launches are KERNELS
+ * (a GEMM that the library splits in two counts twice), so ms / launches is comparable with rocprofv3's kernel stats */
 cogs_status cogs_profile_end(cogs_handle h, cogs_stream stream, float* ms_per_class, int* launches_per_class);
 
 /* ------------------------------------------------------------------ operator level ---- */
