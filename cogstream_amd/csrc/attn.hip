@@ -627,7 +627,9 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
         static const int env_nq = getenv("COGS_ATTN_NQ") ? atoi(getenv("COGS_ATTN_NQ")) : 0;
         // 8 waves x 16 rows: measured faster for hd 128 (no spills, 4 waves per SIMD: causal prefill 2.58 -> 2.29 ms
         // at 15k tokens), slower for hd 72 (0.49 -> 0.52 ms: its fragment reads make the LDS the busiest unit)
-        const bool light = env_nq ? env_nq == 1 : (a.head_dim == 128);
+        // (with pre-scaled Q the 4-wave hd 128 kernel needs 243 VGPRs and no longer spills: 2.34 -> 2.26 ms, so the
+        // light variant is only the default for the classic softmax)
+        const bool light = env_nq ? env_nq == 1 : (a.head_dim == 128 && !a.q_prescaled);
         const bool pre = a.q_prescaled && !a.row_lo;
         if (a.q_prescaled && a.row_lo) return COGS_E_UNSUPPORTED;   // the bias mode is parity-only and unscaled
         p.q_prescaled = pre;
