@@ -45,6 +45,7 @@ struct GemmArgs {
     int M, N, K;
     int nbm, nbn;
     const float* rope_lut; int rope_lut_bytes;   // EPI_ROPE_LUT: global LUT copied to LDS behind the ring at kernel start
+    int group_m;                 // ping-pong kernel: row blocks per group of the tile walk (L2 footprint of an XCD)
     unsigned long long* trace;   // diagnostics (COGS_GEMM_TRACE): per-tile s_memtime stamps of WG 0, waves 0 and 4
     EpiArgs epi;
 };
@@ -392,9 +393,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
     auto tile_origin = [&](int t, int& m0, int& n0) {
         const int xcd = t & 7, q = nb >> 3, r = nb & 7;
         const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
-        const int per_group = GROUP_M * p.nbn;
-        const int first_m = (bid / per_group) * GROUP_M;
-        const int gsz = min(p.nbm - first_m, GROUP_M);
+        const int per_group = p.group_m * p.nbn;
+        const int first_m = (bid / per_group) * p.group_m;
+        const int gsz = min(p.nbm - first_m, p.group_m);
         m0 = (first_m + (bid % per_group) % gsz) * BM3;
         n0 = ((bid % per_group) / gsz) * BN3;
     };
@@ -744,7 +745,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     if (g.M == 1) { ++g_gemm_launches; return cogs_k_gemv(st, g); }
     if (g.rms_gamma) return COGS_E_UNSUPPORTED;   // fused RMSNorm exists for the single-token GEMV only
     GemmArgs p;
-    p.trace = nullptr; p.rope_lut = nullptr; p.rope_lut_bytes = 0;
+    p.trace = nullptr; p.rope_lut = nullptr; p.rope_lut_bytes = 0; p.group_m = GROUP_M;
     const int rc = cogs_fill_epi(g, &p.epi);
     if (rc != COGS_OK) return rc;
     p.A = (const char*)g.A; p.lda = g.lda * es;
@@ -761,6 +762,11 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         p.nbn = (g.N + BN3 - 1) / BN3;
         static const bool env_nostore = getenv("COGS_GEMM_NOSTORE") != nullptr;
         static const bool env_nolut = getenv("COGS_GEMM_NOLUT") != nullptr;
+        // tile walk: groups of group_m row blocks x all column blocks. Measured (in-run A/B, cfg2 shapes): few column
+        // blocks with a long K (fc2: 5 x K 4352) want small groups (2: 0.627 -> 0.591 ms), many column blocks with a
+        // short K (fc1: 17 x K 1152) want 8 (2: +7 %)
+        static const int env_gm = getenv("COGS_GEMM_GROUPM") ? atoi(getenv("COGS_GEMM_GROUPM")) : 0;
+        p.group_m = env_gm > 0 ? env_gm : ((p.nbn <= 6 && g.K >= 2048) ? 2 : GROUP_M);
         int pp_mask = cogs_epi_mask(g);
         p.rope_lut = nullptr; p.rope_lut_bytes = 0;
         if (pp_mask == (EPI_BIAS | EPI_ROPE) && g.rope_lut && g.rope_rowpos && !g.rope_sin && !env_nolut) {
