@@ -166,6 +166,30 @@ class CogReasoner:
         self.active_adapter = adapter_name
 
     # ------------------------------------------------------------------ vision
+    def enable_prefix_cache(self, on: bool = True) -> None:
+        """keep the KV rows of the previous answer prompt and of the previous retrieval prompt (one slot per stage
+        and adapter) and prefill only the rows that changed (llm.PrefixKV)"""
+        self._prefix_on = bool(on)
+        self._prefix_slots = {}
+
+    def _prefix_slot(self, stage: str):
+        if not getattr(self, "_prefix_on", False):
+            return None
+        from .llm import PrefixKV
+        key = (stage, id(self.llm))   # set_adapter() swaps the engine: KV rows of one weight set are not another's
+        slot = self._prefix_slots.get(key)
+        if slot is None:
+            slot = self._prefix_slots[key] = PrefixKV(self.llm)
+        return slot
+
+    def prefix_cache_stats(self):
+        """{stage: (rows reused, prompt rows seen)} summed over the weight sets"""
+        out = {}
+        for (stage, _), v in getattr(self, "_prefix_slots", {}).items():
+            r, n = out.get(stage, (0, 0))
+            out[stage] = (r + v.reused, n + v.seen)
+        return out
+
     def enable_visual_cache(self, max_videos: int = 64) -> None:
         """Streaming-session cache: projected visual tokens per video segment, keyed
         by (content key from the processor, grid t x h x w, merge size, projector in use). The reference re-encodes
@@ -361,7 +385,7 @@ class CogReasoner:
         eos = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
         new = self.llm.generate(emb, max_new_tokens=max_new_tokens, eos_token_id=eos, do_sample=do_sample,
                                 repetition_penalty=self.generation_config.get("repetition_penalty", 1.0),
-                                allowed_ids=allowed_ids, prompt_ids=ids)
+                                allowed_ids=allowed_ids, prompt_ids=ids, prefix=self._prefix_slot("selection"))
         return torch.cat([ids, torch.tensor(new, dtype=torch.int64)]).unsqueeze(0)
 
     def qa_selection(self, current_question=None, hist_qs=None, hist_as=None, tokenizer=None, original_text=None,
@@ -417,5 +441,6 @@ class CogReasoner:
         new = self.llm.generate(embeds, max_new_tokens=int(kwargs.get("max_new_tokens", 1024)), eos_token_id=eos,
                                 do_sample=bool(g.get("do_sample", False)), temperature=float(g.get("temperature", 1.0)),
                                 top_k=int(g.get("top_k", 0) or 0), top_p=float(g.get("top_p", 1.0)),
-                                repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"))
+                                repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"),
+                                prefix=self._prefix_slot("answer"))
         return torch.tensor(new, dtype=torch.int64).unsqueeze(0), selection_module_output

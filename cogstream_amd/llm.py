@@ -29,6 +29,49 @@ class KVCache:
         self.struct.len = length
 
 
+class PrefixKV:
+    """KV rows of the previous prompt, kept so that the next generate() only prefills what differs (SURVEY.md §8f
+    rank 3; the reference rebuilds the whole conversation every turn, evaluate/answer_generate.py:130-148).
+    The reusable prefix is found by comparing the new input embeddings with the previous ones bit for bit on the
+    device: KV row i depends only on rows 0..i and the position i, so every invalidation rule (resized frames, a
+    history turn dropped by the selection stage, another question) is covered by that comparison. Only rows that
+    were PREFILLED are reused -- rows written by decode steps went through the GEMV kernels."""
+
+    def __init__(self, engine: "Qwen2Engine"):
+        self.engine = engine
+        self.cache: Optional[KVCache] = None
+        self.rows: Optional[torch.Tensor] = None   # [n, H] embeddings whose KV rows 0..n-1 are in `cache`
+        self.reused = 0    # rows taken from the cache, summed over calls
+        self.seen = 0      # prompt rows, summed over calls
+
+    def plan(self, embeds: torch.Tensor, need: int) -> int:
+        """-> number of leading rows of `embeds` whose KV is already in self.cache (at most len(embeds) - 2)"""
+        if self.cache is None or self.cache.k.shape[1] < need:
+            old = self.cache
+            self.cache = self.engine.new_cache(need + need // 2)   # sessions grow: leave room for the next turns
+            if old is not None and self.rows is not None:
+                n = self.rows.shape[0]
+                self.cache.k[:, :n].copy_(old.k[:, :n])
+                self.cache.v[:, :n].copy_(old.v[:, :n])
+            else:
+                self.rows = None
+        p = 0
+        if self.rows is not None and self.rows.dtype == embeds.dtype:
+            # at least 2 rows are always prefilled: a 1-row forward is the decode GEMV, whose rounding differs
+            n = min(self.rows.shape[0], embeds.shape[0] - 2)
+            if n > 0:
+                bits = torch.int16 if embeds.element_size() == 2 else torch.int32
+                neq = (self.rows[:n].view(bits) != embeds[:n].view(bits)).any(dim=1)
+                idx = torch.arange(n, device=embeds.device)
+                p = int(torch.where(neq, idx, torch.full_like(idx, n)).min().item())
+        self.seen += embeds.shape[0]
+        self.reused += p
+        return p
+
+    def drop(self):
+        self.rows = None
+
+
 class Qwen2Engine:
     def __init__(self, state: Dict[str, torch.Tensor], cfg: LlmConfig, dtype=torch.bfloat16, device="cuda"):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
@@ -94,15 +137,28 @@ class Qwen2Engine:
                  do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
                  repetition_penalty: float = 1.0, allowed_ids: Optional[Sequence[int]] = None,
                  prompt_ids: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
-                 cache: Optional[KVCache] = None, ignore_eos: bool = False) -> List[int]:
+                 cache: Optional[KVCache] = None, ignore_eos: bool = False,
+                 prefix: Optional[PrefixKV] = None) -> List[int]:
         """GenerationMixin.generate with inputs_embeds: prefill, then one cogs_llm_forward per token.
         Returns the NEW token ids only. Logits processors run in HF order:
-        repetition penalty -> custom (allowed-id mask) -> temperature -> top-k -> top-p."""
+        repetition penalty -> custom (allowed-id mask) -> temperature -> top-k -> top-p.
+        `prefix`: reuse the KV rows of the leading embeddings that are unchanged since the previous call."""
         S = embeds.shape[0]
-        if cache is None:
-            cache = self.new_cache(S + max_new_tokens)
-        pos_start = cache.len + S
-        res = self.forward(embeds, cache)
+        if prefix is not None:
+            assert cache is None
+            embeds = embeds.contiguous()
+            p = prefix.plan(embeds, S + max_new_tokens)
+            cache = prefix.cache
+            cache.reset(p)
+            prefix.rows = None          # not valid while this call is rewriting the cache
+            res = self.forward(embeds[p:], cache)
+            prefix.rows = embeds        # rows 0..S-1 are prefilled; decode rows behind them are never reused
+            pos_start = S
+        else:
+            if cache is None:
+                cache = self.new_cache(S + max_new_tokens)
+            pos_start = cache.len + S
+            res = self.forward(embeds, cache)
         allowed = (torch.tensor(list(allowed_ids), dtype=torch.int32, device=self.device) if allowed_ids is not None else None)
         eos = set(int(e) for e in eos_token_id)
         # token ids stay on the device: the greedy id feeds the next embedding gather and the repetition-penalty

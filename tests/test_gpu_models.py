@@ -114,6 +114,31 @@ def test_llm_greedy_generate_matches_oracle_fp32(dev):
     assert got2 == ref2 and all(t in allowed for t in got2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_llm_prefix_kv_reuse_is_transparent(dev, dtype):
+    """PrefixKV: a prompt that shares its first rows with the previous one prefills only the rest; the KV rows,
+    the logits of the first step and the greedy tokens equal those of a fresh full prefill"""
+    from cogstream_amd.llm import PrefixKV
+    cfg, st, eng = _llm(dev, dtype)
+    torch.manual_seed(21)
+    a = (torch.randn(300, cfg.hidden_size) * 0.5).to(dev, dtype)
+    b = a.clone()
+    b[173:] = (torch.randn(127, cfg.hidden_size) * 0.5).to(dev, dtype)      # differs from row 173 on
+    c = torch.cat([a[:90], (torch.randn(45, cfg.hidden_size) * 0.5).to(dev, dtype)])   # shorter, differs from row 90
+    slot = PrefixKV(eng)
+    d = torch.cat([b, (torch.randn(400, cfg.hidden_size) * 0.5).to(dev, dtype)])   # outgrows the slot's cache
+    for emb, want_p in ((a, 0), (a, 298), (b, 173), (d, 300), (c, 90), (c[:50], 48)):
+        before = slot.reused
+        got = eng.generate(emb, max_new_tokens=8, eos_token_id=[], repetition_penalty=1.05, prefix=slot)
+        assert slot.reused - before == want_p
+        fresh_cache = eng.new_cache(emb.shape[0] + 8)
+        ref = eng.generate(emb, max_new_tokens=8, eos_token_id=[], repetition_penalty=1.05, cache=fresh_cache)
+        assert got == ref
+        n = emb.shape[0]
+        # the reused rows are the same bytes and the re-prefilled rows go through the same kernels as in a full prefill
+        assert torch.equal(slot.cache.k[:, :n], fresh_cache.k[:, :n]) and torch.equal(slot.cache.v[:, :n], fresh_cache.v[:, :n])
+
+
 def test_llm_sampling_runs_and_respects_topk(dev):
     cfg, st, eng = _llm(dev, torch.bfloat16)
     torch.manual_seed(10)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[3]: a multi-turn streaming session (8 turns, one new 8-frame 480p segment and one
 question per turn, growing history + historic-dialogue retrieval) through the whole product path at real
-dimensions (random weights, toy byte tokenizer), with and without the visual-token cache.
+dimensions (random weights, toy byte tokenizer), with and without the visual-token cache and prefix-KV reuse.
     python tools/session_bench.py [turns=8] [frames_per_segment=8] [new_tokens=32]"""
 import os
 import random
@@ -39,21 +39,39 @@ for i in range(turns):
     fr, ts = pr.synthetic_clip(fps_seg, kind="drift", clip_idx=i)
     segs.append((fr, [t + fps_seg * i for t in ts], hist[i % len(hist)]["question"]))
 
-for cached in (False, True):
+def answer(conv, model, hist_n, keep_all):
+    """infer() (evaluate/answer_generate.py:60-76); keep_all: the selection stage is replaced by its "gt" mode with
+    every earlier turn selected -- what a trained selector that keeps the visual history does to the prompt (with
+    random weights the FCC selection is noise and usually strips the history)"""
+    if not keep_all:
+        return infer(conv, model, procr, max_new_tokens=ndec)
+    inputs = procr(conversation=conv, add_system_prompt=True, add_generation_prompt=True, return_tensors="pt")
+    inputs["pixel_values"] = inputs["pixel_values"].to(dev, bf)
+    inputs = model.qa_selection(**inputs, mode="gt", select_gt=list(range(hist_n)), if_visual=True)
+    ids, sel = model.generate(**inputs, max_new_tokens=ndec)
+    return procr.batch_decode(ids, skip_special_tokens=True)[0].strip(), sel
+
+
+for cached, prefix, keep_all in ((False, False, False), (True, False, False), (True, True, False),
+                                 (True, False, True), (True, True, True)):
     model = CogReasoner(enc, proj, eng, lcfg, generation_config=dict(do_sample=False, eos_token_id=[-1], repetition_penalty=1.05))
     if cached:
         model.enable_visual_cache()
+    if prefix:
+        model.enable_prefix_cache()
     random.seed(0)
     torch.manual_seed(0)
     conv = [{"role": "system", "content": "You are a helpful assistant."}]
     lat = []
-    for fr, ts, q in segs:
+    for i, (fr, ts, q) in enumerate(segs):
         conv.append({"role": "user", "content": [{"type": "video", "video": fr, "timestamps": ts}, {"type": "text", "text": q}]})
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out, sel = infer(conv, model, procr, max_new_tokens=ndec)
+        out, sel = answer(conv, model, i, keep_all)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t0)
         conv.append({"role": "assistant", "content": out})
-    print(f"visual cache {'on ' if cached else 'off'}: per-turn answer latency (s) " + " ".join(f"{x:.3f}" for x in lat) +
-          f" | session {sum(lat):.2f} s" + (f" | cache {model.visual_cache_stats}" if cached else ""))
+    print(f"selection {'keep-all' if keep_all else 'FCC     '} visual cache {'on ' if cached else 'off'} prefix KV {'on ' if prefix else 'off'}: "
+          "per-turn answer latency (s) " + " ".join(f"{x:.3f}" for x in lat) + f" | session {sum(lat):.2f} s" +
+          (f" | cache {model.visual_cache_stats}" if cached else "") +
+          (f" | prefix rows reused/seen {model.prefix_cache_stats()}" if prefix else ""))
