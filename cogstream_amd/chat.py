@@ -166,6 +166,11 @@ class CogReasoner:
         self.active_adapter = adapter_name
 
     # ------------------------------------------------------------------ vision
+    def enable_distributed_events(self, rank: int, world: int, group=None) -> None:
+        """spread the K + 1 event-summary sequences of select_events_based_on_summary over `world` ranks that all hold
+        this model and the same inputs (same host RNG state for the k-means seeding): parallel.pooled_means_sharded"""
+        self._event_rank, self._event_world, self._event_group = int(rank), int(world), group
+
     def enable_prefix_cache(self, on: bool = True) -> None:
         """keep the KV rows of the previous answer prompt and of the previous retrieval prompt (one slot per stage
         and adapter) and prefill only the rows that changed (llm.PrefixKV)"""
@@ -271,7 +276,14 @@ class CogReasoner:
         q = self.tokenizer(self.current_question, padding=True, truncation=True, return_tensors="pt", max_length=128)
         segs.append(q["input_ids"].reshape(-1).to(torch.int64))
         emb = ops.gather_rows(self.llm.packed.embed, mm_features, torch.cat(segs).to(self.device))
-        pooled_all = self._bf16_round(self.llm.forward_segments(emb, [int(x.numel()) for x in segs]))  # mean of bf16 is bf16
+        lens = [int(x.numel()) for x in segs]
+        if getattr(self, "_event_world", 1) > 1:   # enable_distributed_events(): the sequences are spread over the ranks
+            from .parallel import pooled_means_sharded
+            pooled_all = pooled_means_sharded(self.llm.forward_segments, list(emb.split(lens)), self._event_rank,
+                                              self._event_world, self._event_group)
+        else:
+            pooled_all = self.llm.forward_segments(emb, lens)
+        pooled_all = self._bf16_round(pooled_all)  # mean of bf16 is bf16
         qvec, pooled = pooled_all[K], pooled_all[:K]
         cos = self._bf16_round(ops.cosine(qvec.contiguous(), pooled.contiguous())).cpu()
         assert cos.shape[0] == K

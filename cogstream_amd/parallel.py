@@ -53,3 +53,49 @@ def gather_tokens(local_tokens: torch.Tensor, grid_size: Tuple[int, int, int], m
     out = torch.empty(world * rows, local_tokens.shape[1], dtype=local_tokens.dtype, device=local_tokens.device)
     dist.all_gather_into_tensor(out, padded, group=group)
     return torch.cat([out[r * rows: r * rows + (e - b) * ppf] for r, (b, e) in enumerate(shards)], dim=0)
+
+
+def partition_sequences(lengths, world: int) -> List[List[int]]:
+    """split independent sequences over `world` ranks, balancing tokens (prefill cost): longest first onto the
+    least-loaded rank, ties to the lower rank / lower index, so every rank derives the same plan"""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world
+    plan: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda j: (load[j], j))
+        plan[r].append(i)
+        load[r] += int(lengths[i])
+    return [sorted(p) for p in plan]
+
+
+def pooled_means_sharded(forward_segments, segments: List[torch.Tensor], rank: int, world: int, group=None) -> torch.Tensor:
+    """Event-summary passes of select_events_based_on_summary (model/cogreasoner_chat.py:303-322) over the ranks
+    (SURVEY.md section 8f rank 3): the K event prompts and the question are independent sequences, so rank r runs ONE
+    var-len forward over its share and a single all-gather of the [*, H] fp32 means follows (K*H*4 bytes: 258 KB at
+    K = 18). `segments`: per-sequence input embeddings [n_i, H], identical on every rank;
+    `forward_segments(cat, lens) -> [len(lens), H] fp32`. Returns [len(segments), H] fp32 in sequence order on every
+    rank, equal to forward_segments over all of them (sequences do not interact)."""
+    lens = [int(x.shape[0]) for x in segments]
+    if world == 1:
+        return forward_segments(torch.cat(segments), lens)
+    plan = partition_sequences(lens, world)
+    mine = plan[rank]
+    H = segments[0].shape[1]
+    dev = segments[0].device
+    width = max(len(p) for p in plan)
+    local = torch.zeros(width, H, dtype=torch.float32, device=dev)
+    if mine:
+        local[: len(mine)] = forward_segments(torch.cat([segments[i] for i in mine]), [lens[i] for i in mine])
+    if local.is_cuda and dist.get_backend(group) == "gloo":   # one-GPU rehearsal: see gather_tokens
+        stage = local.cpu()
+        out = torch.empty(world * width, H, dtype=torch.float32)
+        dist.all_gather_into_tensor(out, stage, group=group)
+        out = out.to(dev)
+    else:
+        out = torch.empty(world * width, H, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(out, local, group=group)
+    res = torch.empty(len(segments), H, dtype=torch.float32, device=dev)
+    for r, p in enumerate(plan):
+        if p:
+            res[torch.tensor(p, device=dev)] = out[r * width: r * width + len(p)]
+    return res

@@ -246,6 +246,11 @@ def test_llm_forward_segments_equals_separate_passes(dev, dtype, tol):
         if dtype == torch.float32:
             assert rel_err(got[i].cpu(), oq.forward(st, seg, **kw)[0].mean(0)) < 1e-4
         o += n
+    # a sequence's mean does not depend on which other sequences share the forward: what lets parallel.
+    # pooled_means_sharded spread them over ranks with identical results
+    parts = list(emb.to(dev, dtype).split(lens))
+    sub = eng.forward_segments(torch.cat([parts[3], parts[0]]), [lens[3], lens[0]])
+    assert torch.equal(sub[0], got[3]) and torch.equal(sub[1], got[0])
 
 
 def test_full_size_encoder_is_frame_separable(dev):
