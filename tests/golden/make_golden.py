@@ -7,6 +7,7 @@ reference does not exist on the GPU box; the fixtures (inputs + expected outputs
 
 Weights are not stored: both sides regenerate them with cogstream_amd.weights.random_*_state(seed) (torch CPU
 generator, same image on both boxes); each fixture stores a weight checksum so RNG drift is detected."""
+import copy
 import json
 import os
 import random
@@ -306,7 +307,92 @@ def golden_e2e():
     save("e2e.npz", **out)
 
 
+def golden_video_io():
+    """Videollama3Qwen2Processor.load_video / _load_multimodal_data (model/processing_cogreasoner.py:326-509) with the
+    decoder replaced: this image has no ffmpeg / cv2 / imageio / decord, so those imports are empty modules and the
+    `ffmpeg` calls the two methods make are answered by cogstream_amd.video_io.select_frames (WHICH frames come out
+    of the filter graph is therefore NOT pinned -- the arithmetic around it is: durations, timestamp grids,
+    max_frames subsampling, temporal padding, per-content windows, the running offset between segments)."""
+    import types
+    import transformers.image_utils as _iu
+    import transformers.video_utils as _vu
+    if not hasattr(_iu, "VideoInput"):
+        _iu.VideoInput = _vu.VideoInput
+    for name in ("cv2", "ffmpeg", "imageio"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if "decord" not in sys.modules:
+        d = types.ModuleType("decord")
+        d.VideoReader, d.cpu = object, (lambda *a, **k: None)
+        sys.modules["decord"] = d
+    import model.processing_cogreasoner as P
+    from cogstream_amd import video_io as vio
+
+    specs = {   # path -> (n native frames, native fps, stream start, container duration)
+        "a.mp4": (75, 25.0, 0.0, 3.0), "b.mp4": (131, 30.0, 0.021, 4.4), "c.mp4": (250, 25.0, 0.0, 10.0),
+        "d.mp4": (40, 10.0, 0.5, 4.0)}
+    vids = {}
+    for k, (n, f, st, du) in specs.items():
+        fr = np.zeros((n, 4, 6, 3), np.uint8)
+        fr[:, 0, 0, 0] = np.arange(n) % 256        # frame number in one pixel: identifies the chosen frames
+        vids[k] = vio.DecodedVideo(fr, f, st, du)
+
+    ff = P.ffmpeg
+    ff.probe = lambda path: vids[path].probe()
+    ff.input = lambda path, **kw: {"path": path, "input": kw, "trim": 0.0, "fps": None}
+    ff.trim = lambda st, start, end: {**st, "trim": start}
+    ff.setpts = lambda st, expr: st
+    ff.filter = lambda st, name, *a, **kw: ({**st, "fps": kw["fps"]} if name == "fps" else st)
+    ff.output = lambda st, *a, **kw: st
+
+    def run(st, capture_stdout=True, quiet=True):
+        v = vids[st["path"]]
+        do_trim = "t" in st["input"]
+        dur = st["input"].get("t", float(v.probe()["format"]["duration"]))
+        idx = vio.select_frames(v, dur, do_trim, st["trim"], st["fps"])
+        return v.frames[idx].tobytes(), None
+    ff.run = run
+
+    me = types.SimpleNamespace(fps=1, max_frames=180)
+    me.load_video = lambda **kw: P.Videollama3Qwen2Processor.load_video(me, **kw)
+    me.load_images = None
+    cases = []
+    for kw in (dict(video_path="a.mp4", fps=1, max_frames=180), dict(video_path="b.mp4", fps=2, max_frames=180),
+               dict(video_path="c.mp4", fps=1, max_frames=4), dict(video_path="c.mp4", fps=1, max_frames=180, start_time=2.0, end_time=7.5),
+               dict(video_path="d.mp4", fps=1, max_frames=180, start_time=0.2), dict(video_path="b.mp4", fps=1, max_frames=180, trim_time=0.6),
+               dict(video_path="c.mp4", fps=2, max_frames=180, temporal_factor=4), dict(video_path="a.mp4", fps=None, max_frames=10)):
+        frames, ts, dur = me.load_video(**kw)
+        cases.append({"args": kw, "frame_ids": [int(f[0, 0, 0]) for f in frames], "timestamps": [float(t) for t in ts],
+                      "duration": float(dur)})
+    conv = [{"role": "system", "content": "You are a helpful assistant."},
+            {"role": "user", "content": [{"type": "video", "video": {"video_path": "a.mp4", "fps": 1, "max_frames": 180}},
+                                         {"type": "text", "text": "Q1?"}]},
+            {"role": "assistant", "content": "A1."},
+            {"role": "user", "content": [{"type": "video", "video": {"video_path": "b.mp4", "fps": 1, "max_frames": 180}},
+                                         {"type": "text", "text": "Q2?"}]},
+            {"role": "assistant", "content": "A2."},
+            {"role": "user", "content": [{"type": "video", "video": {"video_path": "c.mp4", "fps": 1, "max_frames": 180,
+                                                                     "start_time": 0.0, "end_time": 4.0}},
+                                         {"type": "video", "video": {"video_path": "c.mp4", "fps": 1, "max_frames": 180,
+                                                                     "start_time": 5.0, "end_time": 9.0}},
+                                         {"type": "text", "text": "Q3?"}]}]
+    new_conv, all_ts = P.Videollama3Qwen2Processor._load_multimodal_data(me, copy.deepcopy(conv))
+    segs = []
+    for m in new_conv:
+        if isinstance(m["content"], list):
+            for c in m["content"]:
+                if isinstance(c, dict) and c.get("type") == "video":
+                    segs.append({"num_frames": int(c["num_frames"]), "timestamps": [float(t) for t in c["timestamps"]],
+                                 "frame_ids": [int(f[0, 0, 0]) for f in c["video"]]})
+    with open(os.path.join(HERE, "video_io.json"), "w") as f:
+        json.dump({"specs": {k: list(v) for k, v in specs.items()}, "load_video": cases, "conversation": conv,
+                   "segments": segs, "all_timestamps": [float(t) for t in all_ts]}, f, indent=1)
+    print("video_io.json", len(cases), "load_video cases,", len(segs), "segments")
+
+
 if __name__ == "__main__":
+    if "--only-video-io" in sys.argv:
+        golden_video_io()
+        sys.exit(0)
     golden_preprocess()
     if "--only-preprocess" in sys.argv:
         sys.exit(0)
