@@ -57,7 +57,7 @@ const char* cogs_status_string(cogs_status s);
 const char* cogs_version(void);
 
 cogs_status cogs_create(int device, cogs_handle* out);
-cogs_status cogs_destroy(cogs_handle h);
+cogs_status cogs_destroy(cogs_handle h);   /* NULL is accepted (no-op) */
 
 /* Optional per-kernel-class timing of the composite calls below (HIP events on `stream`, recorded
  * around every launch between begin and end). Used by bench.py for the roofline figure; adds a few

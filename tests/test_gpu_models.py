@@ -304,3 +304,57 @@ def test_full_size_llm_decode_as_accurate_as_prefill(dev):
     assert rel_err(got, ref) < 6e-2
     del eng, eng32, cache
     torch.cuda.empty_cache()
+
+
+def test_c_abi_error_behaviour(dev):
+    """Errors are status codes, never exceptions or device faults (include/cogs.h): entry points refuse to run before
+    their weights are loaded, with a missing / short workspace, with shapes the kernels do not take, or with a KV
+    cache that is too small -- and the handle stays usable afterwards. The Python host raises CogsError exactly where
+    the reference would raise from torch (model/cogreasoner_chat.py error behaviour)."""
+    import ctypes as C
+    from cogstream_amd import _lib as L
+    from cogstream_amd import ops
+    INVALID, WORKSPACE = -1, -4
+    h = C.c_void_p()
+    assert L.lib.cogs_create(0, C.byref(h)) == 0
+    st = L.current_stream()
+    nbytes = C.c_size_t()
+    x = torch.zeros(64, 588, device=dev, dtype=torch.bfloat16)
+    grid = (C.c_int64 * 3)(1, 8, 8)
+    ms = (C.c_int64 * 1)(2)
+    # a fresh handle has no weights
+    assert L.lib.cogs_vit_workspace_bytes(h, 64, C.byref(nbytes)) == INVALID
+    assert L.lib.cogs_vit_encode(h, st, x.data_ptr(), L.dtype_code(x.dtype), grid, ms, 1, 0, x.data_ptr(), None, 0) == INVALID
+    assert L.lib.cogs_llm_workspace_bytes(h, 8, 8, C.byref(nbytes)) == INVALID
+    assert L.lib.cogs_project(h, st, x.data_ptr(), 16, x.data_ptr(), None, 0) == INVALID
+    assert L.lib.cogs_destroy(h) == 0
+    assert L.lib.cogs_create(0, None) == INVALID and L.lib.cogs_destroy(None) == 0      # destroy(NULL) is a no-op, like free()
+
+    cfg, _, eng = _llm(dev, torch.bfloat16)
+    hh = eng.handle.h
+    emb = (torch.randn(24, cfg.hidden_size, device=dev) * 0.5).to(torch.bfloat16)
+    logits = torch.empty(cfg.vocab_size, device=dev, dtype=torch.float32)
+    assert L.lib.cogs_llm_workspace_bytes(hh, 24, 24, C.byref(nbytes)) == 0 and nbytes.value > 0
+    ws = torch.empty(nbytes.value, device=dev, dtype=torch.uint8)
+    args = (hh, st, emb.data_ptr(), 24)
+    assert L.lib.cogs_llm_forward(*args, None, logits.data_ptr(), None, None, None, 0) == WORKSPACE
+    assert L.lib.cogs_llm_forward(*args, None, logits.data_ptr(), None, None, ws.data_ptr(), nbytes.value // 2) == WORKSPACE
+    small = eng.new_cache(16)                                    # 24 rows do not fit 16
+    assert L.lib.cogs_llm_forward(*args, C.byref(small.struct), logits.data_ptr(), None, None, ws.data_ptr(), ws.numel()) == INVALID
+    assert small.len == 0
+    assert L.lib.cogs_llm_forward(hh, st, emb.data_ptr(), 0, None, logits.data_ptr(), None, None, ws.data_ptr(), ws.numel()) == INVALID
+    pooled = torch.empty(2, cfg.hidden_size, device=dev, dtype=torch.float32)
+    for cu in ((0, 30, 24), (1, 10, 24), (0, 10, 10, 24)):       # not ending at S / not starting at 0 / empty segment
+        arr = (C.c_int32 * len(cu))(*cu)
+        assert L.lib.cogs_llm_forward_segments(hh, st, emb.data_ptr(), 24, arr, len(cu) - 1, pooled.data_ptr(),
+                                               ws.data_ptr(), ws.numel()) == INVALID
+    # the handle still works, and the host wrapper turns a status into an exception
+    ok = eng.forward(emb)["logits"]
+    assert torch.isfinite(ok).all()
+    with pytest.raises(L.CogsError):
+        eng.forward(emb, eng.new_cache(8))
+    with pytest.raises(L.CogsError):
+        ops.gemm(torch.zeros(8, 40, device=dev, dtype=torch.bfloat16), torch.zeros(16, 40, device=dev, dtype=torch.bfloat16))  # K % 64
+    with pytest.raises(L.CogsError):
+        z = torch.zeros(4, 96, device=dev, dtype=torch.bfloat16)
+        ops.attention(z, z[:, :64], z[:, :64], hq=3, hkv=2, head_dim=32)   # query heads not a multiple of kv heads
