@@ -22,4 +22,10 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 toks = eng.generate(emb, max_new_tokens=ndec, repetition_penalty=1.05, ignore_eos=True)
 torch.cuda.synchronize()
-print("prefill+decode %.1f ms for %d tokens" % ((time.perf_counter() - t0) * 1e3, len(toks)))
+t_all = time.perf_counter() - t0
+t0 = time.perf_counter()
+eng.generate(emb, max_new_tokens=1, repetition_penalty=1.05, ignore_eos=True)
+torch.cuda.synchronize()
+t_pre = time.perf_counter() - t0
+print("prefill+decode %.1f ms for %d tokens; decode alone %.3f ms/token at context %d" % (
+    t_all * 1e3, len(toks), (t_all - t_pre) * 1e3 / max(1, ndec - 1), S))
