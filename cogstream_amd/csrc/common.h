@@ -145,7 +145,10 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) {
+    // x * sigmoid(x) = x / (1 + 2^(-x log2 e)): v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE division (~10 VALU)
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 // status codes shared with include/cogs.h
 #define COGS_OK 0
