@@ -317,8 +317,8 @@ class CogStreamProcessor:
         hist_qs, hist_as, cur_q = process_history_qas(conversation)
         # content keys of the video segments (xxh64 of the raw frame bytes) for the model's visual-token cache
         import xxhash
-        video_keys = [xxhash.xxh64((v.cpu().numpy() if isinstance(v, torch.Tensor) else np.ascontiguousarray(v)).tobytes()).hexdigest()
-                      for v in videos]
+        video_keys = [xxhash.xxh64(memoryview(np.ascontiguousarray(v.cpu().numpy() if isinstance(v, torch.Tensor) else v))
+                                   .cast("B")).hexdigest() for v in videos]   # hashed in place: no copy of the frames
         out = {
             "video_keys": video_keys,
             "input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"],
