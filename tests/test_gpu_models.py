@@ -358,3 +358,55 @@ def test_c_abi_error_behaviour(dev):
     with pytest.raises(L.CogsError):
         z = torch.zeros(4, 96, device=dev, dtype=torch.bfloat16)
         ops.attention(z, z[:, :64], z[:, :64], hq=3, hkv=2, head_dim=32)   # query heads not a multiple of kv heads
+
+
+def test_real_dimension_vit_layers_vs_oracle(dev):
+    """The production kernels at the production shapes against the (reference-pinned) oracle: ViT at VideoLLaMA3
+    dimensions (hidden 1152, 16 heads of 72, MLP 4304 -> padded 4352), 2 layers, 4 frames of the cfg2 grid 22 x 42
+    (924 patches per frame, 3696 rows: the ping-pong GEMM with the rotary LUT epilogue, the ragged 924-row attention
+    blocks, LayerNorm, the 2x2 merge) + the 1152 -> 3584 projector. bf16 within bf16 rounding of the fp32 oracle, and
+    the exact-fp32 mode of the same path within 1e-4."""
+    from cogstream_amd.vision import Projector, VisionEncoder
+    from cogstream_amd.weights import VisionConfig, random_proj_state, random_vit_state
+    from oracle import vision as ov
+    cfg = VisionConfig(num_hidden_layers=2)
+    assert (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads) == (1152, 4304, 16)
+    st = random_vit_state(cfg, seed=13, std=0.03)
+    pst = random_proj_state(cfg.hidden_size, 3584, seed=14, std=0.02)
+    torch.manual_seed(15)
+    grid, merge = torch.tensor([[4, 22, 42]]), torch.tensor([2])
+    pix = torch.rand(4 * 924, 588) * 2 - 1
+    ref_tok = ov.encode(st, pix, grid, merge, heads=16, layers=2, mode=0)
+    ref = ov.project(pst, ref_tok)
+    for dtype, tol in ((torch.bfloat16, 3e-2), (torch.float32, 1e-4)):
+        enc = VisionEncoder(st, cfg, dtype=dtype, device=dev)
+        proj = Projector(pst, dtype=dtype, device=dev)
+        tok = enc(pix.to(dev, dtype), grid, merge)
+        out = proj(tok)
+        assert tok.shape == (4 * 231, 1152) and out.shape == (4 * 231, 3584)
+        assert rel_err(tok.float(), ref_tok) < tol, dtype
+        assert rel_err(out.float(), ref) < tol, dtype
+
+
+def test_real_dimension_llm_layer_vs_oracle(dev):
+    """Qwen2-7B dimensions (hidden 3584, 28 query / 4 kv heads of 128, MLP 18944) with one layer and a 4096-entry
+    vocabulary: a 1100-token prefill (ping-pong GEMMs with the rotary / SwiGLU / residual epilogues, causal GQA
+    attention over 9 query blocks) and three decode steps (GEMV path, split-KV attention) against the oracle."""
+    from cogstream_amd.llm import Qwen2Engine
+    from cogstream_amd.weights import LlmConfig, random_llm_state
+    from oracle import qwen2 as oq
+    cfg = LlmConfig(num_hidden_layers=1, vocab_size=4096, image_token_index=4000, eos_token_id=4001)
+    assert (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_key_value_heads) == (3584, 18944, 28, 4)
+    st = random_llm_state(cfg, seed=16, std=0.02)
+    kw = dict(heads=28, kv_heads=4, layers=1)
+    torch.manual_seed(17)
+    emb = torch.randn(1103, cfg.hidden_size) * 0.5
+    hid, _ = oq.forward(st, emb, **kw)
+    eng = Qwen2Engine(st, cfg, dtype=torch.bfloat16, device=dev)
+    cache = eng.new_cache(1110)
+    res = eng.forward(emb[:1100].to(dev, torch.bfloat16), cache, want_hidden=True)
+    assert rel_err(res["hidden"].float(), hid[:1100]) < 3e-2
+    assert rel_err(res["logits"], oq.logits(st, hid[1099])) < 3e-2
+    for i in range(1100, 1103):
+        r = eng.forward(emb[i:i + 1].to(dev, torch.bfloat16), cache)
+        assert rel_err(r["logits"], oq.logits(st, hid[i])) < 3e-2
