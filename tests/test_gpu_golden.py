@@ -230,3 +230,52 @@ def test_full_size_kmeans_and_mask_match_oracle(dev):
     mask = ops.pixdiff_mask(pix.to(dev), Tp, gh * gw // 4, 0.1, 1, md)
     om = oc.compression_mask(pix, grid, merge, ["video"], minor_frame_indices=minor)
     assert torch.equal(om, mask.cpu().bool()) and 0 < int(mask.sum()) < mask.numel()
+
+
+def test_edge_cases_single_frame_tiny_frame_and_text_only(dev):
+    """Edge cases of the product path on the tiny model: a one-frame video (the reference keeps every token of a
+    t == 1 video, model/cogreasoner_chat.py:400-403), a 20 x 30 frame that the token floor upsizes, static frames
+    (pixel-diff keeps one token per later frame, :413-414), and a text-only question (generate() embeds the ids
+    directly, :798-800) -- which must equal the engine driven by hand."""
+    import numpy as np
+    from cogstream_amd import processing as pr
+    from cogstream_amd.answer_generate import infer
+    from toy_tokenizer import ToyTokenizer
+    model = _tiny_model(dev, torch.bfloat16, 0)
+    tok = ToyTokenizer()
+    proc = pr.CogStreamProcessor(tok, device=dev)
+    one, ts1 = pr.synthetic_clip(1, 20, 30, kind="noise", clip_idx=1)
+    tiny = np.random.default_rng(3).integers(0, 255, (2, 20, 30, 3), dtype=np.uint8)
+    static = np.repeat(pr.synthetic_clip(1, 20, 30, kind="noise", clip_idx=2)[0], 5, axis=0)
+    conv = [{"role": "user", "content": [{"type": "video", "video": one, "timestamps": ts1},
+                                         {"type": "video", "video": tiny, "timestamps": [1.0, 2.0]},
+                                         {"type": "video", "video": static, "timestamps": [3.0, 4.0, 5.0, 6.0, 7.0]},
+                                         {"type": "text", "text": "What is shown?"}]}]
+    inputs = proc(conversation=conv, add_system_prompt=True, add_generation_prompt=True, return_tensors="pt")
+    grids = inputs["grid_sizes"].tolist()
+    assert [g[0] for g in grids] == [1, 2, 5] and all(g[1] % 2 == 0 and g[2] % 2 == 0 for g in grids)
+    assert all(g[1] * g[2] // 4 >= 16 for g in grids)                         # min_tokens floor per frame
+    out, sel = infer(conv, model, proc, max_new_tokens=3, do_sample=False)
+    mask = model.last_debug["compression_mask"].cpu()
+    per = [g[1] * g[2] // 4 for g in grids]
+    a, b = per[0], per[0] + 2 * per[1]
+    assert bool(mask[:a].all())                                                # one-frame video: everything kept
+    st = mask[b:].view(5, per[2])
+    assert bool(st[0].all()) and st[1:].sum(dim=1).tolist() == [1, 1, 1, 1]    # static frames: one token each
+    assert isinstance(out, str) and sel == ""
+    # frames of different sizes in one conversation: the reference asserts that every frame has the same number of
+    # tokens (:549), and so does this path
+    big, tsb = pr.synthetic_clip(2, 112, 224, kind="noise", clip_idx=4)      # 32 tokens per frame against 16
+    conv_bad = [{"role": "user", "content": [{"type": "video", "video": static[:3], "timestamps": [0.0, 1.0, 2.0]},
+                                             {"type": "video", "video": big, "timestamps": [3.0, 4.0]},
+                                             {"type": "text", "text": "What is shown?"}]}]
+    with pytest.raises(AssertionError):
+        infer(conv_bad, model, proc, max_new_tokens=2, do_sample=False)
+    # text-only turn
+    conv_t = [{"role": "user", "content": "Hello there, what can you do?"}]
+    it = proc(conversation=conv_t, add_system_prompt=True, add_generation_prompt=True, return_tensors="pt")
+    assert "pixel_values" not in it and it["total_image_num"] == 0
+    sel_in = model.qa_selection(**it, mode="FCC")
+    ids, _ = model.generate(**sel_in, max_new_tokens=5, do_sample=False)
+    want = model.llm.generate(model.llm.embed_tokens(it["input_ids"].reshape(-1)), max_new_tokens=5, eos_token_id=[257])
+    assert ids[0].tolist() == want
