@@ -356,25 +356,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x128_kernel(GemmArgs p) {
 // ---------------------------------------------------------------------------------------------
 // Ping-pong variant (bf16): 256x256 output tile, 8 waves = two groups of 4 (one wave of each group
 // per SIMD), each wave 128x64. The K stream is cut into 32-wide K-tiles (64-byte LDS rows), 4-slot
-// ring (4 x 32 KiB). Every K-tile is two phases (upper / lower 64 rows of the wave's tile); a phase is
-//     L segment: ds_read the phase's fragments (8 or 4 x b128), issue 2 LDS-DMA pieces, lgkmcnt(0)
+// ring (4 x 32 KiB). Every K-tile is
+//     L segment: ds_read the wave's fragments (12 x b128), issue its 4 LDS-DMA pieces, lgkmcnt(0)
 //     --- s_barrier ---
-//     C segment: 16 MFMA
+//     C segment: 32 MFMA
 //     --- s_barrier ---
 // and group 1 runs ONE BARRIER BEHIND group 0, so on every SIMD one wave is in its C segment while the
-// other is in its L segment: the matrix pipe never waits for LDS/DMA issue. Persistent over tiles with
-// a continuous K-tile stream (prefetch distance 3 K-tiles, one counted vmcnt per K-tile). In-kernel interval stamps
-// (-DCOGS_GEMM_KSTAMPS build, tools/gemm_trace.py): per K-tile the L segments take 330-440 cycles against 258 for a
-// C segment, i.e. the two LDS-DMA issues + fragment reads of a phase, not the MFMAs, set the interval; a 5-slot ring
+// other is in its L segment. Persistent over tiles with a continuous K-tile stream (prefetch distance 3 K-tiles, one
+// counted vmcnt per K-tile). The first version cut a K-tile into two such L/C pairs (upper / lower 64 rows: 16 fewer
+// fragment registers); interval stamps (-DCOGS_GEMM_KSTAMPS build, tools/gemm_trace.py) put its L segments at 330-440
+// cycles against 258 for 16 MFMAs, and with the staging thinned out (timing experiments) an interval still took
+// ~100 cycles more than its MFMAs: the hand-over between the groups costs about as much as the imbalance. One pair
+// per K-tile halves the hand-overs: -3..-6 % on every shape but one (in-run A/B: fc1+GELU 0.588 -> 0.569 ms,
+// out-proj 0.224 -> 0.212, fc2 0.610 -> 0.594, Qwen2 gate/up 3.67 -> 3.45; down-proj unchanged). A 5-slot ring
 // (distance 4) and `buffer_load ... lds` pieces instead of `global_load_lds` were both measured without gain.
 constexpr int BM3 = 256, BN3 = 256;
 constexpr int ROW3 = 64;                          // bytes per LDS row = 32 bf16
 constexpr int SLOT3 = (BM3 + BN3) * ROW3;         // 32 KiB per K-tile
 constexpr int RING3 = 4;                          // ring slots (5 = all 160 KiB of LDS: measured, no gain)
 constexpr int DIST3 = RING3 - 1;                  // prefetch distance in K-tiles
-#ifndef PP_TAIL
-#define PP_TAIL 0   // MFMA rows (x4 MFMAs) of a C segment issued after its closing barrier (1: measured 10 % slower -- the L segment, not the barrier round trip, is what an interval waits for)
-#endif
 
 __device__ __forceinline__ int swz3(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }   // [0,2,3,1]
 
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
     const int w_off = BM3 * ROW3 + (wc * 64) * ROW3 + foff;      // + ni*16*ROW3
 
     f32x4 acc[2][4][4];
-    u32x4 afr[4], wfr[4];
+    u32x4 afr[4], afr2[4], wfr[4];   // A fragments of the upper / lower 64 rows, W fragments
 
     if (st_t >= nb) return;
     if constexpr ((EPI & EPI_ROPE_LUT) != 0) {
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
         stamp();
 #ifdef COGS_GEMM_KSTAMPS
         // diagnostic build only: where does an interval go? sums over the K-tiles of this tile, per wave group
-        unsigned long long ks_L0 = 0, ks_W0 = 0, ks_C0 = 0, ks_X0 = 0, ks_L1 = 0, ks_W1 = 0, ks_C1 = 0, ks_X1 = 0;
+        unsigned long long ks_L0 = 0, ks_W0 = 0, ks_C0 = 0, ks_X0 = 0;
         unsigned long long ks_prev = __builtin_amdgcn_s_memtime();
 #define KSTAMP(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - ks_prev; ks_prev = now_; } while (0)
 #else
@@ -528,80 +528,51 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
 #endif
         for (int kt = 0; kt < KT; ++kt, ++g) {
             const char* base = smem + slot * SLOT3;
-            // ---- phase 0: L segment ----
+            // ---- L segment: the K-tile's 12 fragment reads and this wave's 4 staging pieces ----
 #pragma unroll
             for (int i = 0; i < 4; ++i) wfr[i] = *reinterpret_cast<const u32x4*>(base + w_off + i * 16 * ROW3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) afr[i] = *reinterpret_cast<const u32x4*>(base + a_off + i * 16 * ROW3);
-            // K-tile g+3 (pieces 0,1) -> ring slot of K-tile g-1: its last ds_reads (group 1, previous interval)
-            // were drained by that wave's lgkmcnt(0) BEFORE the barrier that opened this interval (WAR safe).
+#pragma unroll
+            for (int i = 0; i < 4; ++i) afr2[i] = *reinterpret_cast<const u32x4*>(base + a_off + 64 * ROW3 + i * 16 * ROW3);
+            // K-tile g+3 -> ring slot of K-tile g-1: its last ds_reads (group 1, previous interval) were drained by
+            // that wave's lgkmcnt(0) BEFORE the barrier that opened this interval (WAR safe).
             // (Measured: draining LDS reads before the barrier with prefetch distance 3 beats distance 2 with
             // the wait behind the barrier by 3-4 %.)
             stage_half(0);
+            stage_half(1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(afr[0]), "+v"(afr[1]), "+v"(afr[2]), "+v"(afr[3]), "+v"(wfr[0]), "+v"(wfr[1]),
                          "+v"(wfr[2]), "+v"(wfr[3]));
-            KSTAMP(ks_L0);
-            __builtin_amdgcn_s_barrier();
-            KSTAMP(ks_W0);
-            // ---- phase 0: C segment ----
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mi = 0; mi < 4 - PP_TAIL; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[0][mi][ni], 0, 0, 0);
-            // hand the matrix pipe over EARLY: the other group is released while this wave's last PP_TAIL*4 MFMAs are
-            // still queued, so the pipe does not drain for a barrier round trip every interval
-            __builtin_amdgcn_sched_barrier(0);
-            KSTAMP(ks_C0);
-            __builtin_amdgcn_s_barrier();
-            KSTAMP(ks_X0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mi = 4 - PP_TAIL; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[0][mi][ni], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            asm volatile("" ::: "memory");
-            // ---- phase 1: L segment ----
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                afr[i] = *reinterpret_cast<const u32x4*>(base + a_off + 64 * ROW3 + i * 16 * ROW3);
-            stage_half(1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(afr[0]), "+v"(afr[1]), "+v"(afr[2]), "+v"(afr[3]));
+            asm volatile("" : "+v"(afr2[0]), "+v"(afr2[1]), "+v"(afr2[2]), "+v"(afr2[3]));
             // K-tile g+1 must have landed before anyone reads it (interval after the next-but-one barrier for
             // group 0, after the next barrier for group 1): both groups wait at the end of THIS interval --
             // group 1 here (end of its L segment), group 0 at the end of its C segment below.
             const int ahead = total - 1 - g;   // K-tiles after the current one
             if (grp == 1) wait_next_ktile(ahead, kt);
-            KSTAMP(ks_L1);
+            KSTAMP(ks_L0);
             __builtin_amdgcn_s_barrier();
-            KSTAMP(ks_W1);
-            // ---- phase 1: C segment ----
+            KSTAMP(ks_W0);
+            // ---- C segment: 32 MFMAs (upper, then lower 64 rows of the wave's tile) ----
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int mi = 0; mi < 4 - PP_TAIL; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[0][mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[1][mi][ni], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr2[mi]), acc[1][mi][ni], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (grp == 0) wait_next_ktile(ahead, kt);
-            KSTAMP(ks_C1);
+            KSTAMP(ks_C0);
             __builtin_amdgcn_s_barrier();
-            KSTAMP(ks_X1);
+            KSTAMP(ks_X0);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mi = 4 - PP_TAIL; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[1][mi][ni], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             asm volatile("" ::: "memory");
             slot = slot + 1 == RING3 ? 0 : slot + 1;
@@ -609,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
 #ifdef COGS_GEMM_KSTAMPS
         if (tracing && lane == 0 && t == (int)blockIdx.x) {   // first tile of workgroup 0
             unsigned long long* o = p.trace + 192 + grp * 8;
-            o[0] = ks_L0; o[1] = ks_W0; o[2] = ks_C0; o[3] = ks_X0; o[4] = ks_L1; o[5] = ks_W1; o[6] = ks_C1; o[7] = ks_X1;
+            o[0] = ks_L0; o[1] = ks_W0; o[2] = ks_C0; o[3] = ks_X0; o[4] = o[5] = o[6] = o[7] = 0;
         }
 #endif
         // epilogue of this tile; it runs inside this group's next L interval, i.e. beside the other group's C
@@ -687,8 +658,8 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         for (int g = 0; g < 2; ++g) {
             const unsigned long long* o = h + 192 + g * 8;
             const double kt_n = p.K / 32.0;
-            fprintf(stderr, "[gemm kstamps] group %d per K-tile: phase0 L %.0f wait %.0f C %.0f wait %.0f | phase1 L %.0f wait %.0f C %.0f wait %.0f\n",
-                    g, o[0] / kt_n, o[1] / kt_n, o[2] / kt_n, o[3] / kt_n, o[4] / kt_n, o[5] / kt_n, o[6] / kt_n, o[7] / kt_n);
+            fprintf(stderr, "[gemm kstamps] group %d per K-tile: L %.0f wait %.0f C %.0f wait %.0f\n",
+                    g, o[0] / kt_n, o[1] / kt_n, o[2] / kt_n, o[3] / kt_n);
         }
 #endif
         return;
