@@ -755,9 +755,10 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         static const bool env_nosplit = getenv("COGS_GEMM_NOSPLIT") != nullptr;
         const int nb = p.nbm * p.nbn;
         const int rounds = nb / PERSISTENT_WGS, rem = nb % PERSISTENT_WGS;
-        // (pays when a tile is long against a second launch: K >= 2048; measured at K = 1152: -2 %, K = 3584: +5 %,
-        // K = 4352: +2 %, K = 18944: +8 %)
-        if (!env_nosplit && !env_nostore && g.K >= 2048 && rounds >= 2 && rem > 0 && rem * 10 < PERSISTENT_WGS * 7) {
+        // (pays when a tile is long against a second launch and the last round is less than ~45 % full: measured
+        // with the two-segment K loop at K = 1152: -2 %; K = 3584, last round 34 % full: +2 %; K = 18944, 34 %: +6 %;
+        // K = 4352, 51 % full (ViT fc2): -2 %, so it no longer splits)
+        if (!env_nosplit && !env_nostore && g.K >= 2048 && rounds >= 2 && rem > 0 && rem * 100 < PERSISTENT_WGS * 45) {
             const int mb_main = rounds * PERSISTENT_WGS / p.nbn;          // whole row blocks within the full rounds
             const int rows_main = mb_main * BM3, rows_rem = g.M - rows_main;
             if (mb_main > 0 && rows_rem >= 512) {
