@@ -192,7 +192,7 @@ def main() -> None:
         # HBM-side traffic per GEMM launch: PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 read
         # correction) collected with tools/collect_profiles.sh and committed under profiles/
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_f_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r1_g_gemm_traffic.json")
         if world == 1 and T == 64 and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")
         out["roofline"] = {"bound": "mfma",
