@@ -307,6 +307,96 @@ def golden_e2e():
     save("e2e.npz", **out)
 
 
+QWEN2_CASES = {
+    # tag: (LlmConfig overrides, prompt length)  -- "t" = the tiny e2e model; "g" = GQA with 3 query heads per kv head
+    "t": (dict(LLM), 37),
+    "g": (dict(LLM, hidden_size=768, intermediate_size=640, num_attention_heads=6, num_key_value_heads=2,
+               num_hidden_layers=3), 150),
+}
+
+
+def golden_qwen2():
+    """the Qwen2 seams the reference calls, run on the REFERENCE's own model object
+    (Videollama3Qwen2ForCausalLM, cogreasoner_chat.py:591-598; transformers' Qwen2 arithmetic underneath):
+    get_model()(inputs_embeds=, attention_mask=).last_hidden_state (:312-316,322), its mean over the sequence
+    (:317,323), lm_head logits of the last row and of three cached single-token steps (the generate() loop,
+    :802-807). Stored for the fp32 model and for the same model cast to bf16 (how the reference runs on a GPU,
+    evaluate/answer_generate.py:176), both on CPU. The three decode steps are fed the fp32 model's greedy tokens
+    in both precisions so that every stored vector has the same inputs."""
+    out = {"transformers_version": np.array(__import__("transformers").__version__)}
+    for tag, (llm, S) in QWEN2_CASES.items():
+        lcfg = LlmConfig(**llm)
+        lst = random_llm_state(lcfg, seed=7, std=0.05)
+        vst = random_vit_state(VisionConfig(**VIT), seed=3, std=0.05)
+        pst = random_proj_state(VIT["hidden_size"], llm["hidden_size"], seed=1, std=0.05)
+        saved = dict(LLM)
+        LLM.clear(); LLM.update(llm)
+        try:
+            model = build_ref_model(vst, pst, lst)
+        finally:
+            LLM.clear(); LLM.update(saved)
+        g = torch.Generator().manual_seed(900 + S)
+        embeds = torch.randn(S, llm["hidden_size"], generator=g) * 0.5
+        out[f"{tag}_embeds"] = embeds
+        out[f"{tag}_llm_checksum"] = np.float64(checksum(lst))
+        out[f"{tag}_cfg"] = np.array(json.dumps(llm))
+        steps = None
+        for prec, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            m = copy.deepcopy(model).to(dt).eval()
+            e = embeds.to(dt)[None]
+            with torch.no_grad():
+                r = m.get_model()(inputs_embeds=e, attention_mask=torch.ones(1, S, dtype=torch.long), use_cache=True)
+                hid = r.last_hidden_state[0]
+                lg = [m.lm_head(hid[-1:]).float()[0]]
+                pooled = torch.mean(r.last_hidden_state, dim=1)[0]
+                past = r.past_key_values
+                toks = []
+                for i in range(3):
+                    tok = int(lg[-1].argmax()) if steps is None else steps[i]
+                    toks.append(tok)
+                    te = m.get_model().embed_tokens(torch.tensor([[tok]]))
+                    r = m.get_model()(inputs_embeds=te, attention_mask=torch.ones(1, S + i + 1, dtype=torch.long),
+                                      past_key_values=past, use_cache=True)
+                    past = r.past_key_values
+                    lg.append(m.lm_head(r.last_hidden_state[0, -1:]).float()[0])
+            if steps is None:
+                steps = toks
+                out[f"{tag}_step_tokens"] = np.array(toks, dtype=np.int64)
+            out[f"{tag}_hidden_{prec}"] = hid.float()
+            out[f"{tag}_pooled_{prec}"] = pooled.float()
+            out[f"{tag}_logits_{prec}"] = torch.stack(lg)          # [4, vocab]: prefill, then 3 cached steps
+        print(tag, "steps", steps, "bf16-vs-f32 logits rel",
+              float((out[f"{tag}_logits_bf16"] - out[f"{tag}_logits_f32"]).abs().max() / out[f"{tag}_logits_f32"].abs().max()))
+    save("qwen2.npz", **out)
+
+
+def golden_vit_bf16():
+    """the encoder + projector cast to bf16 (evaluate/answer_generate.py:176), block-diagonal semantics (one frame
+    per call of the eager path = the flash path), on the inputs of vit_tiny.npz rounded to bf16 (:70)."""
+    cfg = VisionConfig(**VIT)
+    st = random_vit_state(cfg, seed=3, std=0.05)
+    m = ref_vit(st, cfg).to(torch.bfloat16)
+    gold = np.load(os.path.join(HERE, "vit_tiny.npz"))
+    pix = torch.from_numpy(gold["pixel_values"]).bfloat16()
+    grid, merge = torch.from_numpy(gold["grid_sizes"]), torch.from_numpy(gold["merge_sizes"])
+    outs, row = [], 0
+    with torch.no_grad():
+        for (t, h, w), ms in zip(grid.tolist(), merge.tolist()):
+            for f in range(t):
+                outs.append(m(pix[row:row + h * w], torch.tensor([[1, h, w]]), torch.tensor([ms])))
+                row += h * w
+        block_diag = torch.cat(outs, 0)
+        pst = random_proj_state(cfg.hidden_size, LLM["hidden_size"], seed=1, std=0.05)
+        cfg_ns = types.SimpleNamespace(vision_encoder_config=types.SimpleNamespace(hidden_size=cfg.hidden_size),
+                                       hidden_size=LLM["hidden_size"])
+        proj = ref_chat.MlpGeluProjector(cfg_ns, "mlp2x_gelu").eval()
+        proj.load_state_dict(pst, strict=True)
+        projected = proj.to(torch.bfloat16)(block_diag)
+    f32 = torch.from_numpy(gold["block_diag"])
+    print("vit bf16 vs f32 reference: rel max", float((block_diag.float() - f32).abs().max() / f32.abs().max()))
+    save("vit_tiny_bf16.npz", block_diag=block_diag.float(), projected=projected.float())
+
+
 def golden_video_io():
     """Videollama3Qwen2Processor.load_video / _load_multimodal_data (model/processing_cogreasoner.py:326-509) with the
     decoder replaced: this image has no ffmpeg / cv2 / imageio / decord, so those imports are empty modules and the
@@ -393,10 +483,10 @@ if __name__ == "__main__":
     if "--only-video-io" in sys.argv:
         golden_video_io()
         sys.exit(0)
-    golden_preprocess()
     if "--only-preprocess" in sys.argv:
+        golden_preprocess()
         sys.exit(0)
-    which = sys.argv[1:] or ["vit", "kmeans", "compress", "text", "e2e"]
+    which = sys.argv[1:] or ["preprocess", "vit", "vit_bf16", "kmeans", "compress", "text", "e2e", "qwen2"]
     with torch.no_grad():
         for w in which:
             globals()["golden_" + w]()

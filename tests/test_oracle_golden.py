@@ -151,3 +151,40 @@ def test_merge_lora_equals_unmerged_branch_fp32():
                    lora_scaling=2.0, **kw)[0]
     assert rel_err(a, b) < 1e-5
     assert rel_err(a, oq.forward(st, emb, **kw)[0]) > 0.05
+
+
+def _qwen2_case(g, tag):
+    import json as _json
+    from cogstream_amd.weights import LlmConfig, random_llm_state
+    llm = _json.loads(str(g[f"{tag}_cfg"]))
+    lcfg = LlmConfig(**llm)
+    lst = random_llm_state(lcfg, seed=7, std=0.05)
+    assert abs(float(sum(v.double().abs().sum() for v in lst.values())) - float(g[f"{tag}_llm_checksum"])) < 1e-6
+    return lcfg, lst
+
+
+@pytest.mark.parametrize("tag", ["t", "g"])
+def test_qwen2_oracle_matches_reference(tag):
+    """oracle/qwen2.py against the reference's own model object (tests/golden/qwen2.npz: last_hidden_state,
+    sequence mean, prefill logits and three cached decode steps; model/cogreasoner_chat.py:312-323,802-807)."""
+    from oracle import qwen2 as oq
+    g = _load("qwen2.npz")
+    lcfg, lst = _qwen2_case(g, tag)
+    kw = dict(heads=lcfg.num_attention_heads, kv_heads=lcfg.num_key_value_heads, layers=lcfg.num_hidden_layers,
+              eps=lcfg.rms_norm_eps, theta=lcfg.rope_theta)
+    emb = torch.from_numpy(g[f"{tag}_embeds"])
+    hid, kv = oq.forward(lst, emb, **kw)
+    ref_lg = torch.from_numpy(g[f"{tag}_logits_f32"])
+    assert rel_err(hid, torch.from_numpy(g[f"{tag}_hidden_f32"])) < 2e-5
+    assert rel_err(hid.mean(0), torch.from_numpy(g[f"{tag}_pooled_f32"])) < 2e-5
+    assert rel_err(oq.logits(lst, hid[-1]), ref_lg[0]) < 2e-5
+    for i, tok in enumerate(g[f"{tag}_step_tokens"].tolist()):
+        assert int(ref_lg[i].argmax()) == tok                          # the steps ARE the greedy continuation
+        h1, kv = oq.forward(lst, lst["embed_tokens.weight"][tok][None], past=kv, **kw)
+        assert rel_err(oq.logits(lst, h1[-1]), ref_lg[i + 1]) < 2e-5
+    # the oracle evaluated in bf16 follows the reference evaluated in bf16 (same op order, same roundings):
+    # not bit-equal (CPU bf16 matmul blocking differs with shapes) but far inside the bf16-vs-fp32 distance
+    lst16 = {k: v.bfloat16() for k, v in lst.items()}
+    h16, _ = oq.forward(lst16, emb.bfloat16(), **kw)
+    ref16, ref32 = torch.from_numpy(g[f"{tag}_hidden_bf16"]), torch.from_numpy(g[f"{tag}_hidden_f32"])
+    assert rel_err(h16.float(), ref16) <= 1.0 * rel_err(ref16, ref32)
