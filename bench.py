@@ -51,6 +51,20 @@ def vit_attn_flops(frames: int, per_frame: int, cfg) -> float:
     return 4.0 * cfg.num_hidden_layers * frames * per_frame * per_frame * cfg.hidden_size
 
 
+def frame_header_tokens(t: int) -> int:
+    """'Time <t>.0s:' with the real Qwen2 tokenizer: 'Time', ' ', one token per digit, '.', '0', 's', ':'
+    ('Time 12.0s:' -> 8 tokens; tests/golden/tokenizer.json)"""
+    return 6 + len(str(int(t)))
+
+
+def prompt_tokens(T: int, P: int) -> int:
+    """length of the answer prompt the processor builds for a T-frame clip at 1 fps with P visual tokens per frame
+    and the bench question (chat template, processing_cogreasoner.py:707-730,752-801): default system turn (30) +
+    '<|im_start|>user\n' (3) + per frame header + P + separator (1) + question (7) + '<|im_end|>\n' (2) +
+    generation prompt (3). Pinned against the real tokenizer: 15395 at cfg2 (tests/test_tokenizer_golden.py)."""
+    return 30 + 3 + sum(frame_header_tokens(t) + P + 1 for t in range(T)) + 7 + 2 + 3
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,14 +231,14 @@ def main() -> None:
         eng = Qwen2Engine(random_llm_state(lcfg, seed=2, device=dev, dtype=torch.bfloat16), lcfg,
                           dtype=torch.bfloat16, device=dev)
         torch.cuda.empty_cache()
-        # prompt layout (chat template): system(20) + per frame "Time x.0s:"(8) + P
-        # visual tokens + ","(1), question + generation prompt (~16); text rows are random embeddings
-        S = 20 + T * (8 + P + 1) + 16
+        # prompt layout of the real tokenizer (prompt_tokens above); text rows are random embeddings
+        S = prompt_tokens(T, P)
         embeds = torch.randn(S, lcfg.hidden_size, device=dev, dtype=torch.float32).mul_(0.02).to(torch.bfloat16)
-        pos = 20
+        pos = 33
         for f in range(T):
-            embeds[pos + 8:pos + 8 + P] = mm[f * P:(f + 1) * P]
-            pos += 8 + P + 1
+            hdr = frame_header_tokens(f)
+            embeds[pos + hdr:pos + hdr + P] = mm[f * P:(f + 1) * P]
+            pos += hdr + P + 1
         ndec = args.decode_tokens
         # warm-up (allocations, first-touch), then the timed answer
         eng.generate(embeds[:256], max_new_tokens=4, ignore_eos=True)

@@ -447,12 +447,14 @@ class CogReasoner:
             embeds = self.llm.embed_tokens(new_input_ids.reshape(-1))
         g = dict(self.generation_config)
         g.update({k: v for k, v in kwargs.items() if k in ("do_sample", "temperature", "top_k", "top_p",
-                                                            "repetition_penalty", "eos_token_id", "generator")})
+                                                            "repetition_penalty", "eos_token_id", "generator",
+                                                            "sampler", "seed")})
         eos = g.get("eos_token_id", [])
         eos = [eos] if isinstance(eos, int) else list(eos)
         new = self.llm.generate(embeds, max_new_tokens=int(kwargs.get("max_new_tokens", 1024)), eos_token_id=eos,
                                 do_sample=bool(g.get("do_sample", False)), temperature=float(g.get("temperature", 1.0)),
                                 top_k=int(g.get("top_k", 0) or 0), top_p=float(g.get("top_p", 1.0)),
                                 repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"),
+                                sampler=g.get("sampler", "device"), seed=g.get("seed"),
                                 prefix=self._prefix_slot("answer"))
         return torch.tensor(new, dtype=torch.int64).unsqueeze(0), selection_module_output

@@ -137,12 +137,17 @@ class Qwen2Engine:
                  do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
                  repetition_penalty: float = 1.0, allowed_ids: Optional[Sequence[int]] = None,
                  prompt_ids: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
+                 sampler: str = "device", seed: Optional[int] = None,
                  cache: Optional[KVCache] = None, ignore_eos: bool = False,
                  prefix: Optional[PrefixKV] = None) -> List[int]:
         """GenerationMixin.generate with inputs_embeds: prefill, then one cogs_llm_forward per token.
         Returns the NEW token ids only. Logits processors run in HF order:
         repetition penalty -> custom (allowed-id mask) -> temperature -> top-k -> top-p.
-        `prefix`: reuse the KV rows of the leading embeddings that are unchanged since the previous call."""
+        `prefix`: reuse the KV rows of the leading embeddings that are unchanged since the previous call.
+        Sampling (do_sample): cogs_sample on the device, tokens never visit the host. sampler="device": Philox draws
+        keyed by `seed` (default: one draw of the CPU generator) and the step; sampler="host": the CPU generator
+        (`generator`, default the global one) makes the [vocab] exponential draws of every step exactly as
+        torch.multinomial does in the reference's CPU run, so the sampled ids are the reference's."""
         S = embeds.shape[0]
         if prefix is not None:
             assert cache is None
@@ -169,7 +174,9 @@ class Qwen2Engine:
             seen[:n_prompt] = prompt_ids.reshape(-1).to(self.device)
         toks = torch.empty(max_new_tokens, dtype=torch.int64, device=self.device)
         n_seen, produced = n_prompt, 0
-        check_every = 1 if do_sample else 8
+        check_every = 8
+        if do_sample and sampler == "device" and seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
         need_proc = repetition_penalty != 1.0 or allowed is not None or (do_sample and temperature != 1.0)
         stop_at = None
         for step in range(max_new_tokens):
@@ -178,7 +185,9 @@ class Qwen2Engine:
                 prev = seen[:n_seen] if (n_seen and repetition_penalty != 1.0) else None
                 ops.logits_process(logits, prev, repetition_penalty, allowed, temperature if do_sample else 1.0)
             if do_sample:
-                tok_dev = torch.tensor([self._sample(logits, top_k, top_p, generator)], dtype=torch.int64, device=self.device)
+                tok_dev = ops.sample(logits, top_k or 0, 1.0 if top_p is None else top_p,
+                                     draws=self._draws(generator) if sampler == "host" else None,
+                                     seed=seed or 0, offset=step)
             else:
                 tok_dev = ops.argmax(logits)
             toks[step:step + 1].copy_(tok_dev)
@@ -201,24 +210,8 @@ class Qwen2Engine:
             cache.reset(min(cache.len, pos_start + stop_at - 1))
         return out
 
-    def _sample(self, logits: torch.Tensor, top_k: int, top_p: float, generator) -> int:
-        """TopKLogitsWarper + TopPLogitsWarper + multinomial on the k survivors (k = 20 by default,
-        model/generation_config.json:9-10); the draw uses the host generator like the reference's sampler."""
-        k = top_k if top_k and top_k > 0 else 64
-        val, idx = ops.topk(logits, k)
-        val, idx = val.cpu(), idx.cpu()
-        keep = idx >= 0
-        val, idx = val[keep], idx[keep]
-        probs = torch.softmax(val, dim=-1)
-        if top_p < 1.0:
-            # HF: sort ascending, drop tokens whose cumulative prob <= 1 - top_p, always keep the best one
-            sp, order = torch.sort(probs, descending=False)
-            cum = sp.cumsum(-1)
-            remove = cum <= (1 - top_p)
-            remove[-1] = False
-            drop = torch.zeros_like(remove)
-            drop[order] = remove
-            val = val.masked_fill(drop, float("-inf"))
-            probs = torch.softmax(val, dim=-1)
-        j = int(torch.multinomial(probs, 1, generator=generator))
-        return int(idx[j])
+    def _draws(self, generator) -> torch.Tensor:
+        """parity mode: the [vocab] Exponential(1) draws torch.multinomial(probs, 1) makes on the CPU generator
+        (GenerationMixin._sample, transformers 4.46.3; the reference's CPU path draws from the global generator)"""
+        q = torch.empty(self.cfg.vocab_size, dtype=torch.float32).exponential_(1, generator=generator)
+        return q.to(self.device, non_blocking=True)

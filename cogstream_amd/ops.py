@@ -230,3 +230,29 @@ def topk(logits: torch.Tensor, k: int):
     ws = torch.empty(logits.numel(), device=logits.device, dtype=torch.float32)
     check(L.lib.cogs_topk(current_stream(), ptr(logits), logits.numel(), k, ptr(val), ptr(idx), ptr(ws)), "cogs_topk")
     return val, idx
+
+
+def sample(logits: torch.Tensor, top_k: int = 0, top_p: float = 1.0, draws: Optional[torch.Tensor] = None,
+           seed: int = 0, offset: int = 0, out: Optional[torch.Tensor] = None, want_kept: bool = False):
+    """cogs_sample on a processed fp32 [vocab] row -> int64 [1] token on the device (+ (ids, probs) of the surviving
+    tokens if want_kept). draws: device float [vocab] of Exponential(1) draws (parity with torch.multinomial on the
+    CPU generator) or None (Philox on the device, keyed by seed/offset)."""
+    _need_cuda(logits, draws)
+    n = logits.numel()
+    if out is None:
+        out = torch.empty(1, device=logits.device, dtype=torch.int64)
+    ws = torch.empty(L.lib.cogs_sample_workspace_bytes(), device=logits.device, dtype=torch.uint8)
+    kept_idx = kept_prob = n_kept = None
+    cap = 0
+    if want_kept:
+        cap = n
+        kept_idx = torch.empty(cap, device=logits.device, dtype=torch.int32)
+        kept_prob = torch.empty(cap, device=logits.device, dtype=torch.float32)
+        n_kept = torch.zeros(1, device=logits.device, dtype=torch.int32)
+    check(L.lib.cogs_sample(current_stream(), ptr(logits), n, int(top_k or 0), float(top_p if top_p is not None else 1.0),
+                            ptr(draws), int(seed) & (2 ** 64 - 1), int(offset), ptr(out), ptr(kept_idx), ptr(kept_prob),
+                            ptr(n_kept), cap, ptr(ws)), "cogs_sample")
+    if want_kept:
+        m = int(n_kept.item())
+        return out, kept_idx[:m], kept_prob[:m]
+    return out

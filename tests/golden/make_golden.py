@@ -397,6 +397,230 @@ def golden_vit_bf16():
     save("vit_tiny_bf16.npz", block_diag=block_diag.float(), projected=projected.float())
 
 
+def _rle(ids):
+    """[[id, run], ...] -- prompts are dominated by runs of the <image> id"""
+    out = []
+    for i in ids:
+        if out and out[-1][0] == i:
+            out[-1][1] += 1
+        else:
+            out.append([int(i), 1])
+    return out
+
+
+def golden_tokenizer():
+    """Facts about the REAL Qwen2 tokenizer of the checkpoint (/root/reference/model/{vocab.json,merges.txt,
+    added_tokens.json,tokenizer_config.json}: data) and the reference code driven with it:
+      * the allowed-id set of StructuredLogitsProcessor (qaselect_module_predict.py:86-103), read off the processor
+        object the reference's select_qas hands to generate_language_module;
+      * model/chat_template.json rendered by the tokenizer's jinja engine for a set of conversations
+        (processing_cogreasoner.py:752-801 forwards to tokenizer.apply_chat_template);
+      * token ids of the SURVEY appendix-B3 strings and of the cfg2 (64 frames x 231 tokens) / cfg4 prompts;
+      * prepare_inputs / process_input_ids (cogreasoner_chat.py:121-177,478-511) on a real-tokenizer prompt.
+    Every (text, ids) pair that was tokenised is recorded so that tests can replay the tokenizer by lookup."""
+    from transformers import Qwen2Tokenizer
+    from model.qaselect_module_predict import select_qas as ref_select_qas
+    tok = Qwen2Tokenizer.from_pretrained("/root/reference/model")
+    ct = json.load(open("/root/reference/model/chat_template.json"))["chat_template"]
+    pairs = []
+
+    class Recording:
+        """the real tokenizer, recording every encode / decode that goes through it"""
+        def __call__(self, text, **kw):
+            r = tok(text, **kw)
+            ids = r["input_ids"]
+            pairs.append((text, (ids[0] if hasattr(ids, "shape") and ids.ndim == 2 else ids)))
+            return r
+
+        def encode(self, text, **kw):
+            ids = tok.encode(text, **kw)
+            pairs.append((text, ids))
+            return ids
+
+        def decode(self, ids, **kw):
+            text = tok.decode(ids, **kw)
+            if not kw.get("skip_special_tokens"):
+                pairs.append((text, ids))
+            return text
+
+        def __getattr__(self, k):
+            return getattr(tok, k)
+
+    rec = Recording()
+    out = {"vocab_size": len(tok), "image_token_id": tok.convert_tokens_to_ids("<image>"),
+           "im_start": tok.convert_tokens_to_ids("<|im_start|>"), "im_end": tok.convert_tokens_to_ids("<|im_end|>"),
+           "endoftext": tok.convert_tokens_to_ids("<|endoftext|>")}
+
+    # --- allowed ids, from the reference's own processor object
+    cap = {}
+
+    class FakeModel:
+        device = torch.device("cpu")
+
+        def generate_language_module(self, **kw):
+            cap["allowed"] = list(kw["logits_processor"][0].allowed_token_ids)
+            cap["kw"] = {k: v for k, v in kw.items() if k in ("max_new_tokens", "num_beams", "do_sample", "eos_token_id")}
+            gen = torch.tensor(tok.encode("[yes,0]") + [151645])
+            return torch.cat([kw["input_ids"][0], gen])[None]
+
+    hq = ["What is on the table?", "Who enters the room?"]
+    ha = ["A red cup.", "A man in a blue coat."]
+    cur = "What does he pick up?"
+    sel = ref_select_qas(cur, hq, ha, FakeModel(), tokenizer=rec)
+    out["allowed_ids"] = cap["allowed"]
+    out["select_kwargs"] = cap["kw"]
+    out["select_roundtrip"] = sel
+    out["qa_prompt_len"] = len(tok(ref_format_example({"current_Q": cur, "hist_Qs": hq, "hist_As": ha}))["input_ids"])
+
+    # --- chat template renderings (jinja on the reference's template)
+    convs = {
+        "b3": [{"role": "system", "content": "You are a helpful assistant."},
+               {"role": "user", "content": [{"type": "video", "num_frames": 3, "timestamps": [0.0, 1.0, 2.04]},
+                                            {"type": "text", "text": "Q1?"}]},
+               {"role": "assistant", "content": "A1."}, {"role": "user", "content": "Q2?"}],
+        "default_system": [{"role": "user", "content": [{"type": "video", "num_frames": 2, "timestamps": [12.0, 13.06]},
+                                                        {"type": "text", "text": "What is happening in the video?"}]}],
+        "image_and_stream": [{"role": "user", "content": [{"type": "image", "timestamp": 3.25}, {"type": "image"},
+                                                          {"type": "video", "num_frames": 2}, "plain string item",
+                                                          {"type": "text", "text": "Describe."}]},
+                             {"role": "stream", "content": [{"type": "text", "text": "partial"}]},
+                             {"role": "assistant", "content": "ok"}],
+    }
+    out["templates"] = []
+    for name, conv in convs.items():
+        for sysp in (True, False):
+            for gen in (True, False):
+                txt = tok.apply_chat_template(conv, chat_template=ct, tokenize=False, add_system_prompt=sysp,
+                                              add_generation_prompt=gen, image_token="<image>")
+                out["templates"].append({"name": name, "conversation": conv, "add_system_prompt": sysp,
+                                         "add_generation_prompt": gen, "text": txt})
+
+    # --- appendix B3 strings
+    out["strings"] = {s: rec.encode(s, add_special_tokens=False)
+                      for s in ["Time 12.0s:", ",", "\n", "<|im_start|>assistant\n", "<image>", "[yes,0,5]", "[no]",
+                                "yes", "no", "[", "]", "<|im_end|>"] + [str(i) for i in range(10)]}
+
+    # --- prompt lengths: cfg2 (64 frames x 231) and the cfg4 session (8 turns, 8 frames per turn, P = 256 .. 231)
+    def video_prompt(T, P, question, history=()):
+        conv = []
+        for q, a in history:
+            conv += [{"role": "user", "content": q}, {"role": "assistant", "content": a}]
+        conv.append({"role": "user", "content": [{"type": "video", "num_frames": T, "timestamps": [float(i) for i in range(T)]},
+                                                 {"type": "text", "text": question}]})
+        txt = tok.apply_chat_template(conv, chat_template=ct, tokenize=False, add_system_prompt=True,
+                                      add_generation_prompt=True, image_token="<image>")
+        txt = txt.replace("<image>", "<image>" * P)
+        return txt, rec(txt)["input_ids"]
+
+    q = "What is happening in the video?"
+    out["prompts"] = []
+    for T, P in ((64, 231), (8, 64), (256, 50)):
+        txt, ids = video_prompt(T, P, q)
+        out["prompts"].append({"T": T, "P": P, "question": q, "len": len(ids), "ids_rle": _rle(ids),
+                               "n_image": int(sum(1 for i in ids if i == out["image_token_id"])),
+                               "system_len": len(tok.encode(txt.split("<|im_start|>user")[0]))})
+    hist = json.load(open(os.path.join(HERE, "cfg4_history.json")))
+    out["cfg4_retrieval_prompt_lens"] = []
+    hqs, has = [t["question"] for t in hist["turns"]], [t["answer"] for t in hist["turns"]]
+    for n in range(1, len(hqs) + 1):
+        p = ref_format_example({"current_Q": hqs[n - 1], "hist_Qs": hqs[:n - 1], "hist_As": has[:n - 1]})
+        out["cfg4_retrieval_prompt_lens"].append(len(rec(p)["input_ids"]))
+
+    # --- prompt surgery with the real tokenizer (the reference's prepare_inputs decodes, edits and re-tokenises)
+    img = "<image>" * 4
+    text = ("<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n"
+            f"<|im_start|>user\nTime 0.0s:{img},Time 1.0s:{img}\n{hq[0]}<|im_end|>\n<|im_start|>assistant\n{ha[0]}<|im_end|>\n"
+            f"<|im_start|>user\nTime 2.0s:{img},Time 3.5s:{img}\n{hq[1]}<|im_end|>\n<|im_start|>assistant\n{ha[1]}<|im_end|>\n"
+            f"<|im_start|>user\nTime 14.0s:{img}\n{cur}<|im_end|>\n<|im_start|>assistant\n")
+    out["surgery"] = {"original_text": text, "hist_qs": hq, "hist_as": ha, "current_question": cur, "cases": []}
+    for s in ["[yes,0,1]", "[yes,1]", "[yes]", "[no,0]", "[no]", "[no,0,1]", "[yes,5]"]:
+        ns = types.SimpleNamespace(hist_qs=hq, hist_as=ha, current_question=cur, tokenizer=rec)
+        new_inputs, if_visual = ref_chat.Videollama3MetaForCausalLM.prepare_inputs(ns, s, original_text=text)
+        ids = new_inputs["input_ids"][0].tolist()
+        out["surgery"]["cases"].append({"selection": s, "if_visual": bool(if_visual), "ids_rle": _rle(ids),
+                                        "prompt": tok.decode(ids)})
+    # event-summary prompt (cogreasoner_chat.py:93-119,297-298) through the real tokenizer
+    sp = ref_chat.create_visual_summary_prompt(15 * 50, torch.arange(15, dtype=torch.float32) + 30)
+    out["summary_prompt_len"] = len(rec(sp)["input_ids"])
+    out["pairs"] = [{"text": t, "ids_rle": _rle(list(map(int, (i.tolist() if hasattr(i, "tolist") else i))))} for t, i in pairs]
+    with open(os.path.join(HERE, "tokenizer.json"), "w") as f:
+        json.dump(out, f, ensure_ascii=False, indent=None, separators=(",", ":"))
+    print("tokenizer.json: allowed", out["allowed_ids"], "cfg2 prompt", out["prompts"][0]["len"], "pairs", len(out["pairs"]),
+          os.path.getsize(os.path.join(HERE, "tokenizer.json")), "bytes")
+
+
+def golden_sampling():
+    """HF logits processors / warpers in the order GenerationMixin applies them for the reference's shipped
+    generation_config.json (do_sample, temperature 0.7, top_k 20, top_p 0.8, repetition_penalty 1.05;
+    evaluate/answer_generate.py:74 does not override it), the CPU multinomial draw, and a SAMPLED run of the
+    reference's whole pipeline on the tiny model. transformers here is 5.15 (the reference pins 4.46.3; the four
+    processor classes are unchanged in behaviour)."""
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                        TopKLogitsWarper, TopPLogitsWarper)
+    gc = json.load(open("/root/reference/model/generation_config.json"))
+    V = 4096
+    out = {"generation_config": np.array(json.dumps(gc)), "n_cases": np.int64(0)}
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    for ci, (scale, top_k, top_p, temp, rep) in enumerate([(3.0, 20, 0.8, 0.7, 1.05), (0.5, 20, 0.8, 0.7, 1.05),
+                                                          (6.0, 20, 0.8, 0.7, 1.05), (2.0, 0, 0.8, 0.7, 1.05),
+                                                          (2.0, 50, 1.0, 1.0, 1.0), (2.0, 5, 0.3, 1.3, 1.2),
+                                                          (1.0, 0, 0.95, 1.0, 1.0)]):
+        lg = torch.randn(1, V, generator=g) * scale
+        if ci == 2:
+            lg[0, 100:104] = lg[0].max() + 1.0          # exact ties at the top
+        prev = torch.randint(0, V, (1, 37), generator=g)
+        prev[0, :5] = lg[0].topk(5).indices              # penalise the leaders
+        s = lg.clone()
+        if rep != 1.0:
+            s = RepetitionPenaltyLogitsProcessor(rep)(prev, s)
+        out[f"s{ci}_after_penalty"] = s[0].clone()
+        if temp != 1.0:
+            s = TemperatureLogitsWarper(temp)(prev, s)
+        if top_k:
+            s = TopKLogitsWarper(top_k)(prev, s)
+        kept_k = torch.isfinite(s[0]).nonzero().flatten()
+        if top_p < 1.0:
+            s = TopPLogitsWarper(top_p)(prev, s)
+        kept = torch.isfinite(s[0]).nonzero().flatten()
+        probs = torch.softmax(s, dim=-1)[0]
+        draws = []
+        for seed in range(16):
+            gg = torch.Generator().manual_seed(1000 + seed)
+            draws.append(int(torch.multinomial(probs, 1, generator=gg)))
+        out.update({f"s{ci}_logits": lg[0], f"s{ci}_prev": prev[0], f"s{ci}_params": np.array([top_k, top_p, temp, rep], dtype=np.float64),
+                    f"s{ci}_kept_after_topk": kept_k, f"s{ci}_kept": kept, f"s{ci}_probs": probs[kept], f"s{ci}_draws": np.array(draws)})
+        cases.append((ci, len(kept_k), len(kept)))
+    out["n_cases"] = np.int64(len(cases))
+    print("sampling cases (case, kept after top-k, kept after top-p):", cases)
+
+    # sampled generation of the reference pipeline (tiny model, case "a" of the e2e inputs), global CPU generator
+    vst = random_vit_state(VisionConfig(**VIT), seed=3, std=0.05)
+    pst = random_proj_state(VIT["hidden_size"], LLM["hidden_size"], seed=1, std=0.05)
+    lst = random_llm_state(LlmConfig(**LLM), seed=7, std=0.05)
+    model = build_ref_model(vst, pst, lst)
+    tok = ToyTokenizer()
+    inp = e2e_inputs("a")
+    enc = tok(inp["text"])
+    with torch.no_grad():
+        sel = model.qa_selection(current_question=inp["current_question"], hist_qs=[], hist_as=[], tokenizer=tok,
+                                 original_text=inp["text"], input_ids=enc["input_ids"], attention_mask=enc["attention_mask"],
+                                 mode="NC", all_timestamps=inp["timestamps"])
+        for seed in (11, 12):
+            random.seed(seed)
+            torch.manual_seed(seed)
+            ids, _ = model.generate(pixel_values=inp["pixel_values"], grid_sizes=inp["grid_sizes"], merge_sizes=inp["merge_sizes"],
+                                    modals=["video"], new_input_ids=sel["new_input_ids"], new_attention_mask=sel["new_attention_mask"],
+                                    selection_module_output=sel["selection_module_output"], if_visual=sel["if_visual"],
+                                    total_image_num=inp["T"], max_new_tokens=12, do_sample=True, temperature=gc["temperature"] * 4,
+                                    top_k=gc["top_k"], top_p=gc["top_p"], repetition_penalty=gc["repetition_penalty"],
+                                    eos_token_id=[IM_END])
+            out[f"gen_seed{seed}"] = ids[0]
+            print("sampled tokens, seed", seed, ids[0].tolist())
+    out["gen_temperature"] = np.float64(gc["temperature"] * 4)
+    save("sampling.npz", **out)
+
+
 def golden_video_io():
     """Videollama3Qwen2Processor.load_video / _load_multimodal_data (model/processing_cogreasoner.py:326-509) with the
     decoder replaced: this image has no ffmpeg / cv2 / imageio / decord, so those imports are empty modules and the

@@ -331,7 +331,7 @@ def test_qwen2_vs_reference_fixture(dev, tag, dtype):
         for k in got:
             m, r = _dist(got[k], ref32[k])
             print(f"qwen2[{tag}] fp32 {k}: max {m:.2e} rms {r:.2e}")
-            assert m < 1e-3 and r < 1e-3, (k, m, r)
+            assert m < 1e-4 and r < 1e-4, (k, m, r)          # north_star asks 1e-3; measured 6e-6
         assert lg.argmax(dim=1)[:3].tolist() == g[f"{tag}_step_tokens"].tolist()
     else:
         for k in got:
@@ -352,3 +352,77 @@ def test_vit_bf16_vs_reference_bf16_fixture(dev):
     _as_good_as_reference_bf16(bd.float(), torch.from_numpy(g16["block_diag"]), torch.from_numpy(g["block_diag"]), "vit tokens")
     proj = Projector(random_proj_state(cfg.hidden_size, 256, seed=1, std=0.05), dtype=torch.bfloat16, device=dev)
     _as_good_as_reference_bf16(proj(bd).float(), torch.from_numpy(g16["projected"]), torch.from_numpy(g["projected"]), "projected")
+
+
+def test_sampling_warpers_vs_transformers_fixture(dev):
+    """cogs_logits_process + cogs_sample against transformers' RepetitionPenalty / Temperature / TopK / TopP
+    processors and torch.multinomial on the CPU generator (tests/golden/sampling.npz): the surviving id SET is
+    exact, renormalised probabilities agree to fp32 rounding, and with the generator's exponential draws handed
+    over the sampled id is the reference sampler's for every seed. Cases: the shipped config on peaked / flat /
+    tied rows, no top-k (full-row top-p), top-k only, a one-survivor row, top_p 0.95 over the whole row."""
+    from cogstream_amd import ops
+    g = _load("sampling.npz")
+    for ci in range(int(g["n_cases"])):
+        top_k, top_p, temp, rep = g[f"s{ci}_params"].tolist()
+        lg = torch.from_numpy(g[f"s{ci}_logits"]).to(dev).clone()
+        prev = torch.from_numpy(g[f"s{ci}_prev"]).to(dev)
+        ops.logits_process(lg, prev if rep != 1.0 else None, rep, None, 1.0)
+        assert torch.equal(lg.cpu(), torch.from_numpy(g[f"s{ci}_after_penalty"]))
+        if temp != 1.0:
+            ops.logits_process(lg, None, 1.0, None, temp)
+        tok, kid, kp = ops.sample(lg, int(top_k), top_p, seed=1, offset=0, want_kept=True)
+        order = kid.cpu().argsort()
+        assert kid.cpu()[order].tolist() == g[f"s{ci}_kept"].tolist(), ci                 # exact survivor set
+        assert torch.allclose(kp.cpu()[order], torch.from_numpy(g[f"s{ci}_probs"]), rtol=2e-6, atol=1e-9), ci
+        assert int(tok) in g[f"s{ci}_kept"].tolist()
+        for seed, want in enumerate(g[f"s{ci}_draws"].tolist()):
+            q = torch.empty(lg.numel()).exponential_(1, generator=torch.Generator().manual_seed(1000 + seed))
+            assert int(ops.sample(lg, int(top_k), top_p, draws=q.to(dev))) == want, (ci, seed)
+    # device draws: the empirical distribution over many Philox offsets follows the kept probabilities
+    lg = torch.from_numpy(g["s1_logits"]).to(dev).clone()
+    ops.logits_process(lg, torch.from_numpy(g["s1_prev"]).to(dev), 1.05, None, 0.7)
+    out = torch.empty(4000, dtype=torch.int64, device=dev)
+    for i in range(4000):
+        ops.sample(lg, 20, 0.8, seed=99, offset=i, out=out[i:i + 1])
+    ids, probs = g["s1_kept"].tolist(), g["s1_probs"]
+    cnt = torch.bincount(out.cpu(), minlength=lg.numel())
+    assert int(cnt.sum()) == int(cnt[ids].sum())                                              # only survivors
+    emp = cnt[ids].double() / 4000
+    assert float((emp - torch.from_numpy(probs).double()).abs().max()) < 4 * (0.25 / 4000) ** 0.5
+
+
+def test_sampled_generation_equals_reference_cpu_sampler(dev):
+    """the reference pipeline with do_sample=True (its shipped generation mode, model/generation_config.json:2-12)
+    on the tiny model, CPU generator seeded: sampler='host' makes every step's multinomial draw from the same
+    generator stream, so the 12 sampled ids equal the reference's (fp32 parity mode, eager-global attention)."""
+    from golden.inputs import e2e_inputs
+    from toy_tokenizer import ToyTokenizer
+    g = _load("sampling.npz")
+    gc = __import__("json").loads(str(g["generation_config"]))
+    inp = e2e_inputs("a")
+    model = _tiny_model(dev, torch.float32, 1)
+    tok = ToyTokenizer()
+    enc = tok(inp["text"])
+    sel = model.qa_selection(current_question=inp["current_question"], hist_qs=[], hist_as=[], tokenizer=tok,
+                             original_text=inp["text"], input_ids=enc["input_ids"], attention_mask=enc["attention_mask"],
+                             mode="NC", all_timestamps=inp["timestamps"])
+    for seed in (11, 12):
+        random.seed(seed)
+        torch.manual_seed(seed)
+        ids, _ = model.generate(pixel_values=inp["pixel_values"], grid_sizes=inp["grid_sizes"], merge_sizes=inp["merge_sizes"],
+                                modals=["video"], new_input_ids=sel["new_input_ids"], new_attention_mask=sel["new_attention_mask"],
+                                selection_module_output=sel["selection_module_output"], if_visual=sel["if_visual"],
+                                total_image_num=inp["T"], max_new_tokens=12, do_sample=True,
+                                temperature=float(g["gen_temperature"]), top_k=gc["top_k"], top_p=gc["top_p"],
+                                repetition_penalty=gc["repetition_penalty"], sampler="host")
+        assert ids[0].tolist() == g[f"gen_seed{seed}"].tolist(), seed
+    # production sampler: tokens stay on the device, reproducible from the seed
+    a, _ = model.generate(pixel_values=inp["pixel_values"], grid_sizes=inp["grid_sizes"], merge_sizes=inp["merge_sizes"],
+                          modals=["video"], new_input_ids=sel["new_input_ids"], new_attention_mask=sel["new_attention_mask"],
+                          if_visual=True, total_image_num=inp["T"], max_new_tokens=12, do_sample=True, temperature=2.8,
+                          top_k=20, top_p=0.8, repetition_penalty=1.05, seed=5)
+    b, _ = model.generate(pixel_values=inp["pixel_values"], grid_sizes=inp["grid_sizes"], merge_sizes=inp["merge_sizes"],
+                          modals=["video"], new_input_ids=sel["new_input_ids"], new_attention_mask=sel["new_attention_mask"],
+                          if_visual=True, total_image_num=inp["T"], max_new_tokens=12, do_sample=True, temperature=2.8,
+                          top_k=20, top_p=0.8, repetition_penalty=1.05, seed=5)
+    assert a.tolist() == b.tolist() and a.shape[1] <= 12
