@@ -143,6 +143,71 @@ class CogReasoner:
         self._adapters: Dict[str, tuple] = {"base": (llm, projector)}
         self.active_adapter = "base"
 
+    # ------------------------------------------------------------------ loading
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=None, device=None, attn_implementation: str = "flash_attention_2",
+                        trust_remote_code: bool = True, **unused) -> "CogReasoner":
+        """AutoModelForCausalLM.from_pretrained(model_path, trust_remote_code=True, torch_dtype=torch.bfloat16,
+        attn_implementation="flash_attention_2") of evaluate/answer_generate.py:173-178 for this implementation:
+        config.json / generation_config.json / model.safetensors.index.json + shards of the checkpoint directory.
+        attn_implementation: "flash_attention_2" = per-frame (block-diagonal) ViT attention, the path the reference
+        ships with on GPUs; "eager" = the reference's CPU semantics (global attention + same-frame bias,
+        modeling_videollama3_encoder.py:257-266), for parity runs; "sdpa" is broken in the reference (:348) and
+        refused here. The model is built straight on `device` (default cuda:<current>): the later .to(local_rank)
+        of the reference driver (:183) is then a no-op."""
+        from . import checkpoint as ck
+        from .vision import BLOCK_DIAG, REF_EAGER_GLOBAL
+        modes = {"flash_attention_2": BLOCK_DIAG, "eager": REF_EAGER_GLOBAL}
+        if attn_implementation not in modes:
+            raise ValueError(f"attn_implementation={attn_implementation!r}: use 'flash_attention_2' (block-diagonal) or 'eager'")
+        cfgs = ck.load_configs(path)
+        if torch_dtype is None:
+            torch_dtype = getattr(torch, cfgs["torch_dtype"], torch.bfloat16)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        reader = ck.Checkpoint(path, device=dev)
+        want = ck.expected_tensors(cfgs["vision"], cfgs["llm"], cfgs["tie_word_embeddings"])
+        lacking = sorted(set(want) - set(reader.weight_map))
+        if lacking:
+            raise RuntimeError(f"{path}: checkpoint lacks {len(lacking)} tensors of the module tree, e.g. {lacking[:4]}")
+        vit_v, proj_v, llm_v = ck.state_views(reader, cfgs["tie_word_embeddings"])
+        enc = VisionEncoder(vit_v, cfgs["vision"], dtype=torch_dtype, device=dev, attn_mode=modes[attn_implementation])
+        proj = Projector(proj_v, dtype=torch_dtype, device=dev)
+        eng = Qwen2Engine(llm_v, cfgs["llm"], dtype=torch_dtype, device=dev)
+        reader.check_consumed()
+        reader.close()
+        gen = dict(DEFAULT_GENERATION)
+        gen.update(cfgs["generation"])
+        model = cls(enc, proj, eng, cfgs["llm"], generation_config=gen, use_token_compression=cfgs["use_token_compression"])
+        model.name_or_path = path
+        return model
+
+    def to(self, device=None, *a, **k) -> "CogReasoner":
+        """nn.Module.to of the reference driver (answer_generate.py:183): weights already live on the device chosen at
+        load time; moving a packed model between GPUs is not supported"""
+        if device is not None and not isinstance(device, torch.dtype):
+            d = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+            if d.type != "cuda" or (d.index is not None and d.index != self.device.index):
+                raise ValueError(f"model was loaded on {self.device}; load it with from_pretrained(device={d})")
+        return self
+
+    def eval(self) -> "CogReasoner":
+        return self
+
+    def load_adapter_from_path(self, path: str, adapter_name: str) -> None:
+        """PeftModel.from_pretrained(model, path, adapter_name=...) / model.load_adapter(path, adapter_name=...)
+        (answer_generate.py:181-182): peft adapter directory -> one merged weight set (weights.merge_lora)"""
+        from . import checkpoint as ck
+        base = getattr(self, "name_or_path", None)
+        if base is None:
+            raise ValueError("load_adapter_from_path needs a model made by from_pretrained (the base weights are re-read)")
+        lora, alpha = ck.load_adapter_state(path, device=self.device)
+        reader = ck.Checkpoint(base, device=self.device)
+        _, proj_v, llm_v = ck.state_views(reader)
+        self.load_adapter(dict(llm_v), dict(proj_v), lora, adapter_name, lora_alpha=alpha)
+        reader.close()
+
     # ------------------------------------------------------------------ adapters
     # The peft surface evaluate/answer_generate.py uses (:71-73 set_adapter, :181-182 from_pretrained /
     # load_adapter): an adapter here is a merged copy of the Qwen2 (and projector) weights -- weights.merge_lora --

@@ -621,6 +621,19 @@ def golden_sampling():
     save("sampling.npz", **out)
 
 
+def golden_checkpoint_index():
+    """the checkpoint directory's metadata (data, no weights exist in the repository): tensor names -> shard of
+    model/model.safetensors.index.json, its total_size, and the four JSON configs from_pretrained reads"""
+    m = "/root/reference/model/"
+    idx = json.load(open(m + "model.safetensors.index.json"))
+    out = {"total_size": idx["metadata"]["total_size"], "weight_map": idx["weight_map"]}
+    for n in ("config.json", "generation_config.json", "preprocessor_config.json", "processor_config.json"):
+        out[n] = json.load(open(m + n))
+    with open(os.path.join(HERE, "checkpoint_index.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("checkpoint_index.json:", len(out["weight_map"]), "tensors,", out["total_size"], "bytes")
+
+
 def golden_video_io():
     """Videollama3Qwen2Processor.load_video / _load_multimodal_data (model/processing_cogreasoner.py:326-509) with the
     decoder replaced: this image has no ffmpeg / cv2 / imageio / decord, so those imports are empty modules and the

@@ -426,3 +426,57 @@ def test_sampled_generation_equals_reference_cpu_sampler(dev):
                           if_visual=True, total_image_num=inp["T"], max_new_tokens=12, do_sample=True, temperature=2.8,
                           top_k=20, top_p=0.8, repetition_penalty=1.05, seed=5)
     assert a.tolist() == b.tolist() and a.shape[1] <= 12
+
+
+def test_from_pretrained_equals_the_directly_built_model(dev, tmp_path):
+    """CogReasoner.from_pretrained (evaluate/answer_generate.py:173-183) on a synthesised checkpoint directory of the
+    tiny e2e model: config + index + 3 shards streamed to HBM, every tensor consumed once; the loaded model
+    reproduces the REFERENCE's greedy tokens of e2e case 'a' (fp32 + eager = the reference's CPU semantics), picks up
+    generation_config.json, and a peft adapter directory loads into a merged weight set."""
+    import json
+    from safetensors.torch import save_file
+    from golden.inputs import e2e_inputs
+    from toy_tokenizer import ToyTokenizer
+    from cogstream_amd import checkpoint as ck
+    from cogstream_amd.chat import CogReasoner
+    from cogstream_amd.weights import (LlmConfig, VisionConfig, random_llm_state, random_lora_state, random_proj_state,
+                                       random_vit_state)
+    g = _load("e2e.npz")
+    vcfg, lcfg = VisionConfig(**VIT), LlmConfig(**LLM)
+    d = str(tmp_path / "ckpt")
+    ck.save_checkpoint(d, random_vit_state(vcfg, seed=3, std=0.05), random_proj_state(vcfg.hidden_size, lcfg.hidden_size, seed=1, std=0.05),
+                       random_llm_state(lcfg, seed=7, std=0.05), vcfg, lcfg, generation={"do_sample": False, "eos_token_id": [257]},
+                       n_shards=3, dtype=torch.float32)
+    model = CogReasoner.from_pretrained(d, torch_dtype=torch.float32, attn_implementation="eager", device=dev)
+    assert model.generation_config["do_sample"] is False and model.generation_config["eos_token_id"] == [257]
+    assert model.to(dev.index) is model and model.eval() is model
+    with pytest.raises(ValueError):
+        CogReasoner.from_pretrained(d, attn_implementation="sdpa", device=dev)       # broken in the reference too
+    inp = e2e_inputs("a")
+    tok = ToyTokenizer()
+    enc = tok(inp["text"])
+    sel = model.qa_selection(current_question=inp["current_question"], hist_qs=inp["hist_qs"], hist_as=inp["hist_as"],
+                             tokenizer=tok, original_text=inp["text"], input_ids=enc["input_ids"],
+                             attention_mask=enc["attention_mask"], mode="FCC", all_timestamps=inp["timestamps"])
+    assert sel["selection_module_output"] == str(g["a_selection"])
+    ids, _ = model.generate(pixel_values=inp["pixel_values"], grid_sizes=inp["grid_sizes"], merge_sizes=inp["merge_sizes"],
+                            modals=["video"], new_input_ids=sel["new_input_ids"], new_attention_mask=sel["new_attention_mask"],
+                            selection_module_output=sel["selection_module_output"], if_visual=sel["if_visual"],
+                            total_image_num=inp["T"], max_new_tokens=8, repetition_penalty=1.05)
+    assert ids[0].tolist() == g["a_tokens"].tolist()
+    # bf16 load of the same directory (the reference's torch_dtype=torch.bfloat16) runs the production kernels
+    m16 = CogReasoner.from_pretrained(d, torch_dtype=torch.bfloat16, device=dev)
+    assert m16.dtype == torch.bfloat16 and m16.vision_encoder.attn_mode == 0
+    # adapter directory -> merged weight set, switchable like peft's set_adapter
+    ad = str(tmp_path / "adapter")
+    os.makedirs(ad)
+    lora = random_lora_state(lcfg, r=4, proj_dims=(vcfg.hidden_size, lcfg.hidden_size))
+    save_file({k: v.contiguous() for k, v in lora.items()}, os.path.join(ad, "adapter_model.safetensors"))
+    json.dump({"r": 4, "lora_alpha": 8}, open(os.path.join(ad, "adapter_config.json"), "w"))
+    model.load_adapter_from_path(ad, "full_module")
+    model.set_adapter("full_module")
+    emb = model.llm.embed_tokens(enc["input_ids"].reshape(-1))
+    a = model.llm.forward(emb)["logits"].clone()
+    model.set_adapter("base")
+    b = model.llm.forward(emb)["logits"]
+    assert rel_err(a, b) > 1e-3                                                       # the adapter changes the logits
