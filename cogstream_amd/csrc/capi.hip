@@ -1,6 +1,6 @@
 // C-ABI layer of libcogs_hip.so (see include/cogs.h): argument checking, workspace carving and
 // the per-model launch sequences (ViT encoder, projector, Qwen2 forward). No torch types, no
-// exceptions, no device synchronisation.
+// exceptions, no stream synchronisation (host tables travel through a pinned, event-guarded ring).
 #include "../../include/cogs.h"
 #include "common.h"
 #include "kernels.h"
@@ -28,8 +28,14 @@ struct cogs_ctx {
     std::vector<cogs_llm_layer> llm_layers;
     float* llm_inv_freq = nullptr;  // device [head_dim/2]
     int llm_nfreq = 0; float llm_theta = 0.f;
-    // host staging kept alive across async copies
-    std::vector<int32_t> h_cu, h_lo, h_hi;
+    // pinned host staging for small host->device tables (segment boundaries): a ring of slots, each guarded by an
+    // event recorded behind the copy that reads it, so a slot is never rewritten while a queued copy still needs it
+    static constexpr int STAGE_SLOTS = 4;
+    void* stage_host[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_cap[STAGE_SLOTS] = {0, 0, 0, 0};
+    hipEvent_t stage_ev[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_busy[STAGE_SLOTS] = {false, false, false, false};
+    int stage_next = 0;
     // optional per-kernel-class event profiling (bench/roofline only)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;      // pairs
@@ -63,6 +69,29 @@ struct ProfScope {
     }
 };
 #define PROF(cls) ProfScope _prof_scope(h, st, cls)
+
+// copy `bytes` of host data to the device on `st` through the handle's pinned ring (no stream synchronisation)
+static int stage_h2d(cogs_ctx* c, hipStream_t st, void* dst, const void* src, size_t bytes) {
+    const int s = c->stage_next;
+    c->stage_next = (s + 1) % cogs_ctx::STAGE_SLOTS;
+    if (c->stage_busy[s]) {
+        if (hipEventSynchronize(c->stage_ev[s]) != hipSuccess) return COGS_E_HIP;
+        c->stage_busy[s] = false;
+    }
+    if (c->stage_cap[s] < bytes) {
+        if (c->stage_host[s]) (void)hipHostFree(c->stage_host[s]);
+        c->stage_host[s] = nullptr; c->stage_cap[s] = 0;
+        const size_t cap = bytes < 4096 ? 4096 : bytes * 2;
+        if (hipHostMalloc(&c->stage_host[s], cap, hipHostMallocDefault) != hipSuccess) return COGS_E_HIP;
+        c->stage_cap[s] = cap;
+    }
+    if (!c->stage_ev[s] && hipEventCreateWithFlags(&c->stage_ev[s], hipEventDisableTiming) != hipSuccess) return COGS_E_HIP;
+    memcpy(c->stage_host[s], src, bytes);
+    if (hipMemcpyAsync(dst, c->stage_host[s], bytes, hipMemcpyHostToDevice, st) != hipSuccess) return COGS_E_HIP;
+    if (hipEventRecord(c->stage_ev[s], st) != hipSuccess) return COGS_E_HIP;
+    c->stage_busy[s] = true;
+    return COGS_OK;
+}
 
 namespace {
 
@@ -148,6 +177,10 @@ cogs_status cogs_profile_end(cogs_handle h, cogs_stream stream, float* ms_per_cl
 cogs_status cogs_destroy(cogs_handle h) {
     if (!h) return COGS_OK;
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < cogs_ctx::STAGE_SLOTS; ++i) {
+        if (h->stage_ev[i]) { (void)hipEventSynchronize(h->stage_ev[i]); (void)hipEventDestroy(h->stage_ev[i]); }
+        if (h->stage_host[i]) (void)hipHostFree(h->stage_host[i]);
+    }
     if (h->vit_inv_freq) (void)hipFree(h->vit_inv_freq);
     if (h->llm_inv_freq) (void)hipFree(h->llm_inv_freq);
     delete h;
@@ -366,13 +399,13 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
     const bool use_lut = dt == COGS_DT_BF16 && attn_mode == COGS_ATTN_BLOCK_DIAG && hd % 4 == 0 &&
                          maxpos * (hd / 4) * 8 <= 27 * 1024;
 
-    // cu_seqlens (:439-440), same-frame ranges for the eager-global mode, rotary tables (:405-434)
-    h->h_cu.assign(1, 0);
+    // cu_seqlens (:439-440), same-frame ranges for the eager-global mode, rotary tables (:405-434): all written by
+    // kernels on `st` from the grid -- no host staging, so back-to-back encodes with different grids cannot race
     int max_seq = 0;
     {
         int64_t row = 0;
+        int frame0 = 0;
         const bool need_rows = attn_mode == COGS_ATTN_REF_EAGER_GLOBAL;
-        if (need_rows) { h->h_lo.resize(N); h->h_hi.resize(N); }
         for (int v = 0; v < V; ++v) {
             const int t = (int)grid_sizes[3 * v], gh = (int)grid_sizes[3 * v + 1], gw = (int)grid_sizes[3 * v + 2];
             const int per = gh * gw;
@@ -383,17 +416,9 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
                 COGS_TRY(cogs_k_vit_rope_lut(st, lo, (int)row, t, gh, gw, (int)merge_sizes[v], v == 0 ? lut : nullptr, maxpos,
                                              h->vit_inv_freq, h->vit_nfreq));
             }
-            for (int f = 0; f < t; ++f) {
-                if (need_rows)
-                    for (int r = 0; r < per; ++r) { h->h_lo[row + r] = (int32_t)row; h->h_hi[row + r] = (int32_t)(row + per); }
-                row += per;
-                h->h_cu.push_back((int32_t)row);
-            }
-        }
-        if (hipMemcpyAsync(cu, h->h_cu.data(), h->h_cu.size() * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess) return COGS_E_HIP;
-        if (need_rows) {
-            if (hipMemcpyAsync(lo, h->h_lo.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess) return COGS_E_HIP;
-            if (hipMemcpyAsync(hi, h->h_hi.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess) return COGS_E_HIP;
+            { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_vit_segments(st, cu, need_rows ? lo : nullptr, need_rows ? hi : nullptr, (int)row, frame0, t, per)); }
+            row += (int64_t)t * per;
+            frame0 += t;
         }
     }
 
@@ -590,19 +615,15 @@ static cogs_status llm_forward_impl(cogs_handle h, cogs_stream stream, const voi
     int max_seg = 0;
     if (nseg > 0) {
         if (kv || !cu_host || cu_host[0] != 0 || cu_host[nseg] != S || nseg > S) return COGS_E_INVALID;
-        h->h_cu.assign(cu_host, cu_host + nseg + 1);
-        h->h_lo.resize(S);
         for (int sgm = 0; sgm < nseg; ++sgm) {
             const int b = cu_host[sgm], e = cu_host[sgm + 1];
             if (e <= b) return COGS_E_INVALID;
             max_seg = e - b > max_seg ? e - b : max_seg;
-            for (int i = b; i < e; ++i) h->h_lo[i] = i - b;
         }
-        // the staging vectors live in the handle; the stream is synchronised before they can change again
-        if (hipStreamSynchronize(st) != hipSuccess) return COGS_E_HIP;
-        if (hipMemcpyAsync(cu_d, h->h_cu.data(), (nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(pos_d, h->h_lo.data(), (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess)
-            return COGS_E_HIP;
+        // segment boundaries through the pinned ring (the caller's array may die when this call returns);
+        // per-row positions from them on the device
+        COGS_TRY(stage_h2d(h, st, cu_d, cu_host, (size_t)(nseg + 1) * sizeof(int32_t)));
+        { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_seg_positions(st, cu_d, nseg, pos_d)); }
     }
 
     if (hipMemcpyAsync(x, embeds, (size_t)S * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return COGS_E_HIP;

@@ -160,5 +160,17 @@ __device__ __forceinline__ float silu_f(float x) {
 #define COGS_DT_BF16 0
 #define COGS_DT_F32 1
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, device): raise it once per device the calling thread
+// is on (bit per device ordinal). Racing threads may both set it -- the call is idempotent.
+#include <atomic>
+static inline void cogs_ensure_dyn_lds(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}
+
 static inline int cogs_hip_check(hipError_t e) { return e == hipSuccess ? COGS_OK : COGS_E_HIP; }
 #define COGS_LAUNCH_CHECK() cogs_hip_check(hipGetLastError())

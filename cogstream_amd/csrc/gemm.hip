@@ -607,22 +607,16 @@ namespace {
 template <typename T, int EPI>
 void launch_small(hipStream_t st, const GemmArgs& p, int grid) {
     const size_t lds = 4 * TILE_BYTES;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    cogs_ensure_dyn_lds((const void*)gemm_tn_kernel<T, EPI>, (int)lds, attr_done);
     ++g_gemm_launches;
     hipLaunchKernelGGL((gemm_tn_kernel<T, EPI>), dim3(grid), dim3(256), lds, st, p);
 }
 template <typename T, int EPI>
 void launch_big(hipStream_t st, const GemmArgs& p, int grid) {
     const size_t lds = 3 * SLAB2;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_256x128_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    cogs_ensure_dyn_lds((const void*)gemm_tn_256x128_kernel<T, EPI>, (int)lds, attr_done);
     static const int env_wgs = getenv("COGS_GEMM_WGS") ? atoi(getenv("COGS_GEMM_WGS")) : PERSISTENT_WGS;
     const int wgs = env_wgs <= 0 ? grid : (grid < env_wgs ? grid : env_wgs);   // 0 = one tile per workgroup
     ++g_gemm_launches;
@@ -631,11 +625,8 @@ void launch_big(hipStream_t st, const GemmArgs& p, int grid) {
 template <int EPI>
 void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
     const size_t lds = RING3 * SLOT3 + ((EPI & EPI_ROPE_LUT) ? 28 * 1024 : 0);   // ring (+ rotary LUT, <= 28 KiB)
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    cogs_ensure_dyn_lds((const void*)gemm_tn_pp_kernel<EPI>, (int)lds, attr_done);
     static const bool env_trace = getenv("COGS_GEMM_TRACE") != nullptr;
     if (env_trace) {
         static unsigned long long* dbuf = nullptr;

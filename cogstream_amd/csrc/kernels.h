@@ -78,6 +78,10 @@ int cogs_k_pack_rows(hipStream_t st, int in_dtype, int out_dtype, const void* in
                      long ld_out, int rows, int cols_in, int cols_out);
 int cogs_k_vit_rope_table(hipStream_t st, float* cos_t, float* sin_t, int row0, int t, int gh, int gw, int ms,
                           const float* inv_freq, int n_freq);
+// cu_seqlens[frame0+1 .. frame0+t] (and cu[0] for the first video) + optional same-frame row ranges, on the device
+int cogs_k_vit_segments(hipStream_t st, int* cu, int* lo, int* hi, int row0, int frame0, int t, int per);
+// pos[i] = i - cu[segment(i)]
+int cogs_k_seg_positions(hipStream_t st, const int* cu, int nseg, int* pos);
 int cogs_k_vit_rope_lut(hipStream_t st, int* rowpos, int row0, int t, int gh, int gw, int ms, float* lut, int maxpos,
                         const float* inv_freq, int n_freq);
 int cogs_k_llm_rope_table(hipStream_t st, float* cos_t, float* sin_t, const int* pos, int pos0, int rows,

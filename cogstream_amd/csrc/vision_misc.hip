@@ -91,6 +91,30 @@ __global__ __launch_bounds__(256) void llm_rope_kernel(float* cos_t, float* sin_
     }
 }
 
+// cu_seqlens (modeling_videollama3_encoder.py:439-440) and the same-frame row ranges of the eager-global mode for one
+// video, written on the device: frame f of the video covers rows [row0 + f*per, row0 + (f+1)*per)
+__global__ __launch_bounds__(256) void vit_segments_kernel(int* __restrict__ cu, int* __restrict__ lo, int* __restrict__ hi,
+                                                           int row0, int frame0, int t, int per) {
+    const long total = (long)t * per;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 <= t) {
+        if (i0 > 0) cu[frame0 + i0] = row0 + (int)i0 * per;
+        else if (frame0 == 0) cu[0] = 0;
+    }
+    if (!lo) return;
+    for (long i = i0; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i / per);
+        lo[row0 + i] = row0 + f * per;
+        hi[row0 + i] = row0 + (f + 1) * per;
+    }
+}
+
+// positions restart at every segment: pos[i] = i - cu[s] for cu[s] <= i < cu[s+1]; one workgroup per segment
+__global__ __launch_bounds__(256) void seg_positions_kernel(const int* __restrict__ cu, int* __restrict__ pos) {
+    const int b = cu[blockIdx.x], e = cu[blockIdx.x + 1];
+    for (int i = b + threadIdx.x; i < e; i += 256) pos[i] = i - b;
+}
+
 inline int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -136,6 +160,22 @@ int cogs_k_vit_rope_lut(hipStream_t st, int* rowpos, int row0, int t, int gh, in
     if (lut)
         hipLaunchKernelGGL(vit_rope_lut_kernel, dim3(grid_for((long)maxpos * n_freq)), dim3(256), 0, st, lut, maxpos, inv_freq,
                            n_freq);
+    return COGS_LAUNCH_CHECK();
+}
+
+int cogs_k_vit_segments(hipStream_t st, int* cu, int* lo, int* hi, int row0, int frame0, int t, int per) {
+    if (t <= 0 || per <= 0 || !cu) return COGS_E_INVALID;
+    const long total = lo ? (long)t * per : (long)t + 1;
+    long g = (total + 255) / 256, gmin = ((long)t + 1 + 255) / 256;   // the first t+1 threads write cu
+    if (g < gmin) g = gmin;
+    if (g > 4096 && gmin <= 4096) g = 4096;
+    hipLaunchKernelGGL(vit_segments_kernel, dim3((unsigned)g), dim3(256), 0, st, cu, lo, hi, row0, frame0, t, per);
+    return COGS_LAUNCH_CHECK();
+}
+
+int cogs_k_seg_positions(hipStream_t st, const int* cu, int nseg, int* pos) {
+    if (nseg <= 0) return COGS_OK;
+    hipLaunchKernelGGL(seg_positions_kernel, dim3(nseg), dim3(256), 0, st, cu, pos);
     return COGS_LAUNCH_CHECK();
 }
 

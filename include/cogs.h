@@ -19,7 +19,10 @@
  *   - `stream` is a hipStream_t; work is enqueued on it in call order;
  *   - `dtype` is the storage + arithmetic input type of activations/weights:
  *     COGS_DT_BF16 (production; fp32 accumulation) or COGS_DT_F32 (parity mode, exact-f32 MFMA);
- *   - a handle is bound to one device; calls on one handle are not thread-safe.
+ *   - a handle is bound to one device; calls on one handle are not thread-safe. Calls may be queued on a stream
+ *     back to back without synchronising: every device table a call needs is built by kernels on that stream or
+ *     travels through a pinned, event-guarded staging ring of the handle, and the workspace passed to a call is
+ *     only touched by work queued on the call's stream (so one workspace = one stream at a time).
  */
 #ifndef COGS_H_
 #define COGS_H_
@@ -156,7 +159,9 @@ cogs_status cogs_mean_rows(cogs_stream stream, int dtype, const void* x, int64_t
 cogs_status cogs_cosine(cogs_stream stream, const float* a, const float* b, int n, int D, float* out);
 
 /* Time-aware k-means steps (model/kmeans_with_time.py:4-137); the host keeps the RNG draws.
- * feats [T, PD] (dtype), centres fp32 [K, PD], ts/centre_ts fp32. K <= 32, T <= 1024. */
+ * feats [T, PD] (dtype), centres fp32 [K, PD], ts/centre_ts fp32. Any T and K (the reference has no limit: a
+ * 600-frame session clusters into K = 40). Distances are direct sums of (x - c)^2, not torch.cdist's
+ * |x|^2 + |c|^2 - 2 x.c: see DESIGN.md section 2 (near-tie study) for where the reference's own rounding decides. */
 cogs_status cogs_kmeans_workspace_bytes(int T, int64_t PD, int K, size_t* bytes);
 /* dist2[T,K] = squared L2 distance to the centres; centre_rows (device int32 [K], nullable)
  * selects feature rows as centres instead of `centres` (k-means++ init, :46-50) */

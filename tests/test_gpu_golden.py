@@ -480,3 +480,80 @@ def test_from_pretrained_equals_the_directly_built_model(dev, tmp_path):
     model.set_adapter("base")
     b = model.llm.forward(emb)["logits"]
     assert rel_err(a, b) > 1e-3                                                       # the adapter changes the logits
+
+
+def test_kmeans_beyond_the_old_caps_matches_oracle(dev):
+    """a 600-frame session (three 180-frame segments and more): K = ceil(600/15) = 40 > 32 clusters, and T = 1500 rows
+    > 1024 -- the reference has no limit (model/kmeans_with_time.py); assignments and near-centroid picks bit-equal
+    to the oracle's"""
+    from oracle import kmeans as ok
+    from cogstream_amd.kmeans import kmeans_with_time_min_max, select_additional_frames
+    for T, P, D, K, bf in ((600, 4, 96, 40, True), (1500, 2, 64, 100, False)):
+        g = torch.Generator().manual_seed(T)
+        centres = torch.randn(K, 1, D, generator=g) * 3
+        which = torch.arange(T) * K // T
+        feats = centres[which] + 0.4 * torch.randn(T, P, D, generator=g)
+        if bf:
+            feats = feats.bfloat16()
+        ts = torch.arange(T, dtype=torch.float32)
+        random.seed(1); torch.manual_seed(1)
+        cf, ct, assign = kmeans_with_time_min_max(feats.to(dev), ts, K)
+        picks = select_additional_frames(feats.to(dev), cf, assign, 2)
+        random.seed(1); torch.manual_seed(1)
+        ocf, oct_, oassign = ok.kmeans_with_time_min_max(feats, ts, K)
+        opicks = ok.select_additional_frames(feats, ocf, oassign, 2)
+        assert torch.equal(assign.cpu(), oassign), (T, K)
+        assert rel_err(cf.float(), ocf) < 1e-5 and rel_err(ct, oct_) < 1e-6
+        assert [sorted(p.cpu().tolist()) for p in picks] == [sorted(p.tolist()) for p in opicks]
+
+
+def test_kmeans_near_ties_follow_the_exact_distance(dev):
+    """tests/golden/kmeans_ties.npz (tests/golden/kmeans_tie_study.py ran the reference on these 400 rows of real
+    width 179 200, planted at relative margins 1e-2 .. 1e-6 between two centres): the HIP assignment is the EXACT
+    (fp64) nearest centre for every row; it equals the reference's for every row whose margin is >= 1e-3, which is
+    where the reference's own |x|^2+|c|^2-2x.c sgemm still decides correctly (below that it mis-assigns 3-40 % of
+    the rows against the exact distance: the table in DESIGN.md section 2)."""
+    from golden.tie_inputs import K, P, D, tie_inputs
+    from cogstream_amd import ops
+    g = _load("kmeans_ties.npz")
+    x = tie_inputs()["features"].view(-1, P * D)
+    assert abs(float(x.double().abs().sum()) - float(g["checksum"])) < 1e-3
+    T = x.shape[0]
+    xd = x.to(dev)
+    ws = ops.kmeans_workspace(T, P * D, K, dev)
+    d2 = ops.kmeans_sqdist(xd, xd[:K].contiguous(), None, K, ws)
+    zeros = torch.zeros(T, device=dev)
+    assign, counts = ops.kmeans_assign(d2, zeros, torch.zeros(K, device=dev), 2.0)
+    assign = assign.cpu().numpy()
+    assert int(counts.sum()) == T
+    assert (assign == g["exact_assign"]).all()
+    safe = g["margin"] >= 1e-3
+    assert safe.sum() > 60 and (assign[safe] == g["ref_assign_8t"][safe]).all()
+    table = g["table"]            # rows: [hi, lo, n, ref8!=exact, ref1!=exact, ref8!=ref1, hip32!=exact, hip64!=exact]
+    assert table[:, 6].sum() == 0 and table[:2, 3].sum() == 0 and table[2:, 3].sum() > 0
+
+
+def test_back_to_back_encodes_with_different_grids_do_not_race(dev):
+    """two cogs_vit_encode calls queued on one stream without synchronising in between, different grids (different
+    cu_seqlens / row-range tables), both attention modes: each equals the same call made alone -- the tables are
+    built by kernels on the stream, nothing is staged in handle-owned host memory"""
+    from cogstream_amd.vision import BLOCK_DIAG, REF_EAGER_GLOBAL, VisionEncoder
+    from cogstream_amd.weights import VisionConfig, random_vit_state
+    cfg = VisionConfig(**VIT)
+    enc = VisionEncoder(random_vit_state(cfg, seed=3, std=0.05), cfg, dtype=torch.float32, device=dev)
+    g = torch.Generator().manual_seed(2)
+    ga, gb = torch.tensor([[3, 4, 6]]), torch.tensor([[2, 6, 4], [5, 2, 2]])
+    pa = (torch.rand(72, 588, generator=g) * 2 - 1).to(dev)
+    pb = (torch.rand(68, 588, generator=g) * 2 - 1).to(dev)
+    ma, mb = torch.tensor([2]), torch.tensor([2, 2])
+    for mode in (BLOCK_DIAG, REF_EAGER_GLOBAL):
+        torch.cuda.synchronize()
+        a = enc(pa, ga, ma, attn_mode=mode).clone()      # the workspace is shared: keep the outputs, not the scratch
+        b = enc(pb, gb, mb, attn_mode=mode).clone()
+        a2 = enc(pa, ga, ma, attn_mode=mode).clone()
+        torch.cuda.synchronize()
+        alone_b = enc(pb, gb, mb, attn_mode=mode)
+        torch.cuda.synchronize()
+        alone_a = enc(pa, ga, ma, attn_mode=mode)
+        torch.cuda.synchronize()
+        assert torch.equal(a, alone_a) and torch.equal(a2, alone_a) and torch.equal(b, alone_b)
