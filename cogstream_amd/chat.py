@@ -177,8 +177,9 @@ class CogReasoner:
         eng = Qwen2Engine(llm_v, cfgs["llm"], dtype=torch_dtype, device=dev)
         reader.check_consumed()
         reader.close()
-        gen = dict(DEFAULT_GENERATION)
-        gen.update(cfgs["generation"])
+        # HF: generation_config.json, when present, IS the generation config (nothing is merged in from elsewhere);
+        # without the file generate() runs on GenerationConfig defaults (greedy, no penalty)
+        gen = dict(cfgs["generation"]) if cfgs["generation"] else dict(do_sample=False, eos_token_id=[cfgs["llm"].eos_token_id])
         model = cls(enc, proj, eng, cfgs["llm"], generation_config=gen, use_token_compression=cfgs["use_token_compression"])
         model.name_or_path = path
         return model
