@@ -6,6 +6,7 @@
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -25,6 +26,69 @@ def _stale(target: Path, deps) -> bool:
         return True
     t = target.stat().st_mtime
     return any(d.stat().st_mtime > t for d in deps)
+
+
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+EPI_BIAS, EPI_RES, EPI_ROPE, EPI_ROPE_LUT = 1, 2, 4, 512      # csrc/gemm_epilogue.h
+_VMEM = re.compile(r"^\s*(global_load|global_store|buffer_load|buffer_store|flat_load|flat_store|scratch_)")
+
+
+def epi_pair_vmem_ops(epi: int) -> int:
+    """csrc/gemm_epilogue.h::epi_pair_vmem_ops<EPI>()"""
+    return 16 + (4 if epi & EPI_BIAS else 0) + (16 if epi & EPI_RES else 0) + \
+        ((8 if epi & EPI_ROPE_LUT else 32) if epi & EPI_ROPE else 0)
+
+
+def check_epilogue_vmem_counts(obj: Path):
+    """The ping-pong GEMM relaxes the first s_waitcnt vmcnt of a tile by the number of vector-memory instructions the
+    previous tile's epilogue issued (csrc/gemm.hip, wait_next_ktile). That number is a compile-time formula; the
+    epilogue's loads and stores are plain C++, so this check disassembles gemm.o and counts what hipcc really
+    emitted between the region markers (s_nop 8|9 ... s_nop 10) of every gemm_tn_pp_kernel<EPI>. vmcnt(N) waits until
+    at most N operations are outstanding, so the wait stays CORRECT as long as the epilogue issues AT LEAST the
+    assumed number (more = the wait also covers the oldest extra ones, e.g. a spill reload at the region start:
+    scratch_* instructions count on vmcnt too); fewer than assumed would let LDS-DMA pieces of the next K-tile be
+    read before they land. Returns (unsafe, slack, regions): unsafe = [(kernel EPI, region kind, emitted, assumed)]
+    with emitted < assumed, slack = the same tuples with emitted > assumed."""
+    tmp = obj.parent / "epi_check"
+    tmp.mkdir(exist_ok=True)
+    work = tmp / obj.name
+    work.write_bytes(obj.read_bytes())
+    r = subprocess.run([OBJDUMP, "--offloading", str(work)], capture_output=True, text=True)
+    bundles = sorted(tmp.glob(obj.name + ".*gfx950*"))
+    if r.returncode != 0 or not bundles:
+        raise RuntimeError(f"cannot extract the gfx950 code object of {obj.name}: {r.stdout}{r.stderr}")
+    dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(bundles[0])], capture_output=True, text=True)
+    if dis.returncode != 0:
+        raise RuntimeError(dis.stderr)
+    bad, slack, regions, kern_epi = [], [], 0, None
+    state, count = None, 0
+    for line in dis.stdout.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+        if m:
+            k = re.search(r"gemm_tn_pp_kernelILi(\d+)E", m.group(1))
+            kern_epi, state = (int(k.group(1)) if k else None), None
+            continue
+        if kern_epi is None:
+            continue
+        ins = line.split("//")[0].strip()
+        if re.match(r"^s_nop (8|9)\b", ins):
+            state, count = ("rope" if ins.split()[1] == "9" else "plain"), 0
+        elif re.match(r"^s_nop 10\b", ins) and state:
+            epi = kern_epi if (state == "rope" or not kern_epi & EPI_ROPE) else kern_epi & ~(EPI_ROPE | EPI_ROPE_LUT)
+            want = epi_pair_vmem_ops(epi)
+            regions += 1
+            if count < want:
+                bad.append((kern_epi, state, count, want))
+            elif count > want:
+                slack.append((kern_epi, state, count, want))
+            state = None
+        elif state and _VMEM.match(ins):
+            count += 1
+    if regions == 0:
+        raise RuntimeError("no epilogue region markers found in gemm.o (was the marker asm removed?)")
+    for f in tmp.glob("*"):
+        f.unlink()
+    return bad, slack, regions
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -52,6 +116,28 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             for warn in ex.map(cc, jobs):
                 if warn and verbose:
                     print(warn)
+    if any(sj.stem == "gemm" for sj, _ in jobs) and "COGS_EPI_NOPAIR" not in " ".join(FLAGS):
+        gemm_o = OBJ / "gemm.o"
+        bad, slack, regions = check_epilogue_vmem_counts(gemm_o)
+        stamp = OBJ / "gemm.epi_check.txt"
+        if bad:
+            msg = "; ".join(f"kernel<EPI={k}> {kind} region: {got} vector-memory instructions, the wait assumes {want}"
+                            for k, kind, got, want in bad)
+            if os.environ.get("COGS_STRICT_BUILD") == "1":
+                raise RuntimeError("epilogue vmem-count check failed: " + msg)
+            print("WARNING: epilogue vmem-count check failed (" + msg + "); rebuilding gemm.hip with the conservative "
+                  "s_waitcnt (-DCOGS_EPI_CONSERVATIVE)", flush=True)
+            cmd = [HIPCC] + FLAGS + ["-DCOGS_EPI_CONSERVATIVE", "-c", str(CSRC / "gemm.hip"), "-o", str(gemm_o)]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on gemm.hip:\n{r.stdout}\n{r.stderr}")
+            stamp.write_text("conservative: " + msg + "\n")
+        else:
+            extra = "; ".join(f"<EPI={k}> {kind}: {got} emitted vs {want} assumed" for k, kind, got, want in slack)
+            stamp.write_text(f"ok: {regions} epilogue regions, every region emits at least the assumed vector-memory "
+                             f"instructions ({len(slack)} with more: {extra or 'none'})\n")
+            if verbose:
+                print(stamp.read_text().strip(), flush=True)
     objs = [OBJ / (s.stem + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB)] + [str(o) for o in objs]
@@ -61,6 +147,32 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+LIB_NOPAIR = HERE / "libcogs_hip_nopair.so"
+
+
+def build_nopair(force: bool = False) -> Path:
+    """A/B library for tests/test_gpu_ops.py: the same sources with -DCOGS_EPI_NOPAIR, i.e. the ping-pong GEMM stores
+    through the generic per-half epilogue and always takes the conservative s_waitcnt. Outputs must equal the default
+    build's bit for bit (a wrong relaxed vmcnt would show up as a difference). Only gemm.hip is compiled again."""
+    build()
+    o = OBJ / "gemm_nopair.o"
+    hdrs = sorted(CSRC.glob("*.h")) + [HERE.parent / "include" / "cogs.h"]
+    if force or _stale(o, [CSRC / "gemm.hip"] + hdrs):
+        cmd = [HIPCC] + FLAGS + ["-DCOGS_EPI_NOPAIR", "-c", str(CSRC / "gemm.hip"), "-o", str(o)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on gemm.hip (nopair):\n{r.stdout}\n{r.stderr}")
+    objs = [o if s.stem == "gemm" else OBJ / (s.stem + ".o") for s in sorted(CSRC.glob("*.hip"))]
+    if force or _stale(LIB_NOPAIR, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB_NOPAIR)] + [str(x) for x in objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_NOPAIR
+
+
 if __name__ == "__main__":
     p = build(force="--force" in sys.argv, verbose="-v" in sys.argv)
     print(p)
+    if "--nopair" in sys.argv:
+        print(build_nopair(force="--force" in sys.argv))

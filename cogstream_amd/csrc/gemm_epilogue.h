@@ -274,6 +274,12 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
 template <int EPI>
 __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int nb, int lane, f32x4 (&acc)[4][4]) {
     typedef bf16_t T;
+    // Region markers for the build-time check (cogstream_amd/build.py::check_epilogue_vmem_counts): the relaxed
+    // vmcnt of the ping-pong kernel's next-tile waits is only right if hipcc emits exactly epi_pair_vmem_ops<EPI>()
+    // vector-memory instructions between these two markers; the build disassembles gemm.o and counts them.
+    // s_nop 8 / 9 = begin (without / with rotary loads), s_nop 10 = end. ("memory": nothing moves across.)
+    if constexpr ((EPI & EPI_ROPE) != 0) asm volatile("s_nop 9" ::: "memory");
+    else asm volatile("s_nop 8" ::: "memory");
     const int r = lane & 15, g4 = lane >> 4;
     const int wcol = 16 * (g4 & 1) + 8 * (g4 >> 1);
     char* const cbase = p.C + ((long)mb * p.ldc + nb) * 2;
@@ -405,6 +411,12 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int nb, int lane, f32x4 (&acc0)[4][4],
                                                    f32x4 (&acc1)[4][4]) {
     typedef bf16_t T;
+    // Region markers for the build-time check (cogstream_amd/build.py::check_epilogue_vmem_counts): the relaxed
+    // vmcnt of the ping-pong kernel's next-tile waits is only right if hipcc emits exactly epi_pair_vmem_ops<EPI>()
+    // vector-memory instructions between these two markers; the build disassembles gemm.o and counts them.
+    // s_nop 8 / 9 = begin (without / with rotary loads), s_nop 10 = end. ("memory": nothing moves across.)
+    if constexpr ((EPI & EPI_ROPE) != 0) asm volatile("s_nop 9" ::: "memory");
+    else asm volatile("s_nop 8" ::: "memory");
     const int r = lane & 15, g4 = lane >> 4;
     const int wcol = 16 * (g4 & 1) + 8 * (g4 >> 1);
     char* const cbase = p.C + ((long)mb * p.ldc + nb) * 2;
@@ -549,6 +561,7 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
         if constexpr (HAS_LOADS) { if (b + 2 < NB) load_batch(b + 2); }   // before this batch's stores (see above)
         store_batch(b);
     }
+    asm volatile("s_nop 10" ::: "memory");
 }
 
 // vector-memory instructions (loads + stores; they share the in-order vmcnt queue) one epilogue_pair_fast<EPI> issues
@@ -562,7 +575,7 @@ constexpr int epi_pair_vmem_ops() {
 template <typename T, int EPI>
 __device__ __forceinline__ int epilogue_wave_pair(const EpiArgs& p, int mb, int nb, int M, int N, int lane,
                                                   f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4]) {
-#ifndef COGS_EPI_NOPAIR   // (A/B builds only)
+#ifndef COGS_EPI_NOPAIR   // (A/B builds; also the build's fallback when the vmem-count check fails)
     if constexpr (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0) {
         bool fast = mb + 128 <= M && nb + 64 <= N && (N & 31) == 0 && (p.ldc & 7) == 0 &&
                     (reinterpret_cast<unsigned long>(p.C) & 15) == 0;

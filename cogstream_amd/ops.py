@@ -36,8 +36,10 @@ def k_slab(dtype) -> int:
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
          residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_f32: bool = False,
          rope_cos: Optional[torch.Tensor] = None, rope_sin: Optional[torch.Tensor] = None, rope_cols: int = 0,
-         head_dim: int = 0, rope_lut: Optional[torch.Tensor] = None, rope_rowpos: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)  (see cogs_gemm in include/cogs.h)"""
+         head_dim: int = 0, rope_lut: Optional[torch.Tensor] = None, rope_rowpos: Optional[torch.Tensor] = None,
+         lib=None) -> torch.Tensor:
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)  (see cogs_gemm in include/cogs.h). lib: another build of the library
+    (A/B tests only)"""
     _need_cuda(a, w, bias, residual, out)
     M, K = a.shape
     N = w.shape[0]
@@ -57,7 +59,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     d.rope_cos, d.rope_sin, d.rope_cols, d.head_dim = ptr(rope_cos), ptr(rope_sin), rope_cols, head_dim
     d.rope_lut, d.rope_rowpos = ptr(rope_lut), ptr(rope_rowpos)
     d.rope_maxpos = int(rope_lut.shape[0]) if rope_lut is not None else 0
-    check(L.lib.cogs_gemm(current_stream(), C.byref(d)), "cogs_gemm")
+    fn = L.lib.cogs_gemm
+    if lib is not None:
+        fn = lib.cogs_gemm
+        fn.restype, fn.argtypes = L.SIGNATURES["cogs_gemm"]
+    check(fn(current_stream(), C.byref(d)), "cogs_gemm")
     return out
 
 

@@ -440,3 +440,51 @@ def test_gpu_preprocessing_bit_exact_vs_pil_path(dev, shape):
     assert torch.equal(got["pixel_values"].cpu(), torch.from_numpy(ref["pixel_values"]))
     got16 = preprocess_videos_gpu([torch.from_numpy(frames).to(dev)], out_dtype=torch.bfloat16)
     assert torch.equal(got16["pixel_values"].cpu(), torch.from_numpy(ref["pixel_values"]).bfloat16())
+
+
+def test_pair_epilogue_and_relaxed_vmcnt_equal_the_generic_build_bit_for_bit(dev):
+    """The ping-pong GEMM's lean pair epilogue lets the next tile's first K-tile waits leave its stores in flight
+    (`s_waitcnt vmcnt(8 + ops)`, csrc/gemm.hip). libcogs_hip_nopair.so is the same source built with
+    -DCOGS_EPI_NOPAIR: generic epilogue, conservative waits. On the cfg2 ViT shapes (plain, bias, bias+residual,
+    bias+GELU, bias+rotary table, bias+rotary LUT) and a Qwen2-prefill shape the two builds must agree bit for bit:
+    a wait that lets a wave read a ring slot before its LDS-DMA pieces landed would show up here."""
+    import ctypes as C
+    from cogstream_amd import _lib as L2
+    from cogstream_amd.build import LIB_NOPAIR
+    ops = _ops()
+    assert LIB_NOPAIR.exists(), "build it with `python -m cogstream_amd.build --nopair` (__graft_entry__.build does)"
+    alt = C.CDLL(str(LIB_NOPAIR))
+    stamp = LIB_NOPAIR.parent / "csrc" / "build" / "gemm.epi_check.txt"
+    assert stamp.read_text().startswith("ok:"), stamp.read_text()      # the build's disassembly check passed
+    torch.manual_seed(5)
+    M = 59136 // 4                                     # a quarter of cfg2's patches: 58 row blocks, several rounds
+    hd, heads = 72, 16
+    H, I = 1152, 4352
+    g = torch.Generator(device=dev).manual_seed(1)
+    rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).bfloat16()
+    x, big = rnd(M, H), rnd(M, I)
+    nf, maxpos = hd // 4, 42
+    hpos = torch.randint(0, 22, (M,), generator=g, device=dev)
+    wpos = torch.randint(0, maxpos, (M,), generator=g, device=dev)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(nf, dtype=torch.float32, device=dev) / nf))
+    lut_ang = torch.arange(maxpos, dtype=torch.float32, device=dev)[:, None] * inv_freq[None, :]
+    lut = torch.stack([lut_ang.cos(), lut_ang.sin()], -1).contiguous()
+    rowpos = (hpos | (wpos << 16)).to(torch.int32)
+    ang = torch.cat([hpos[:, None].float() * inv_freq, wpos[:, None].float() * inv_freq], 1)
+    table = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+    cases = [
+        ("qkv+rope table", dict(a=x, w=rnd(3 * H, H), bias=rnd(3 * H), rope_cos=table, rope_cols=2 * H, head_dim=hd)),
+        ("qkv+rope lut", dict(a=x, w=rnd(3 * H, H), bias=rnd(3 * H), rope_cos=table, rope_cols=2 * H, head_dim=hd,
+                              rope_lut=lut, rope_rowpos=rowpos)),
+        ("out-proj+res", dict(a=x, w=rnd(H, H), bias=rnd(H), residual=rnd(M, H))),
+        ("fc1+gelu", dict(a=x, w=rnd(I, H), bias=rnd(I), act=L2.ACT_GELU_TANH)),
+        ("fc2+res", dict(a=big, w=rnd(H, I), bias=rnd(H), residual=rnd(M, H))),
+        ("plain", dict(a=x, w=rnd(3584, H))),
+        ("proj gelu-erf", dict(a=x, w=rnd(3584, H), bias=rnd(3584), act=L2.ACT_GELU_ERF)),
+    ]
+    for name, kw in cases:
+        for rep in range(2):
+            a = ops.gemm(**kw)
+            b = ops.gemm(**kw, lib=alt)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b), (name, rep, float((a.float() - b.float()).abs().max()))
