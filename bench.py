@@ -14,6 +14,12 @@ over ranks. Default `--scaling weak`: the clip grows with N (64 frames per GPU: 
 256-frame configs[2] clip), so per-GPU work is the N = 1 workload; `--scaling strong` shards the 64-frame clip
 itself (8 frames per GPU at N = 8). The Qwen2 section, the pre-processing line and the CPU baseline are N = 1 only.
 
+`--config cfg3` makes BASELINE.json configs[2] the timed workload instead: ONE 256-frame 480p clip (16 384-token budget
+-> 140x280 per frame, 200 patches / 50 tokens per frame), its frames sharded over the N ranks (32 per GPU at N = 8),
+one all-gather -- strong scaling of a fixed clip. With the default config the same measurement rides along as the
+extra key "cfg3" at every N that divides 256 (a few untimed-region steps after the headline), so the N = 1..8 runs
+carry both curves: the headline weak-scaling one and configs[2]'s.
+
 The same JSON line also carries, measured after the timed steps on rank 0:
   answer_tokens_per_s   greedy decode rate of the Qwen2-7B path (prefill of the full ~15k-token
                         interleaved prompt, then 128 tokens, EOS ignored), e2e_s the whole answer latency;
@@ -77,6 +83,10 @@ def main() -> None:
     ap.add_argument("--clip", default="noise", choices=["noise", "drift"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --frames per GPU (clip of frames*N), strong = --frames in total")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"],
+                    help="cfg2: BASELINE configs[1] (64-frame clip; the metric's config). cfg3: configs[2], one 256-frame "
+                         "clip at the 16384-token budget (140x280 per frame) sharded over the ranks")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the extra configs[2] measurement of the default run")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,29 +120,37 @@ def main() -> None:
     vcfg, lcfg = VisionConfig(), LlmConfig()
     from cogstream_amd.parallel import frame_shards, gather_tokens
     from cogstream_amd.preprocess_gpu import preprocess_videos_gpu
+    cfg3 = args.config == "cfg3"
+    if cfg3:
+        args.frames, args.scaling = 256, "strong"
     weak = world > 1 and args.scaling == "weak"
     T = args.frames * world if weak else args.frames          # frames of the whole clip
-    f_lo, f_hi = frame_shards(T, world)[rank]
-    t_loc = f_hi - f_lo
-
-    # ---- synthetic clip -> pixel_values, outside the timed region. Each rank makes only its own frames (clip
-    # content is per 64-frame chunk, so the N = 1 clip is chunk 0) and pre-processes them on its GPU; at N = 1
-    # the host PIL path runs too and the two results are compared bit for bit. ----
-    chunks = sorted({f // 64 for f in range(f_lo, f_hi)})
-    parts = {c: processing.synthetic_clip(64, kind=args.clip, clip_idx=c)[0] for c in chunks}
-    frames = np.stack([parts[f // 64][f % 64] for f in range(f_lo, f_hi)])
     torch.zeros(1).to(dev)    # context / allocator warm-up, so that h2d_ms is the copy
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    dframes = torch.from_numpy(frames).to(dev)
-    torch.cuda.synchronize()
-    h2d_ms = (time.perf_counter() - t0) * 1e3
-    # token budget: the processor's 16384 visual tokens per 64 frames (cfg2 -> 308x588 per frame), scaled with the
-    # shard so that every rank picks the same per-frame size
-    feats = preprocess_videos_gpu([dframes], merge_size=2, max_tokens=16384 * t_loc // 64)
-    pix = feats["pixel_values"]   # bf16 on the GPU (evaluate/answer_generate.py:70 casts pixel_values to bf16)
-    _, gh, gw = (int(v) for v in feats["grid_sizes"][0])
-    grid_loc = torch.tensor([[t_loc, gh, gw]])
+
+    def make_clip(T_clip: int, budget_frames: int):
+        """this rank's frames of a T_clip-frame synthetic clip -> pixel_values on the GPU, outside the timed region.
+        Each rank makes only its own frames (clip content is per 64-frame chunk, so the N = 1 cfg2 clip is chunk 0)
+        and pre-processes them on its GPU. Token budget: the processor's 16384 visual tokens per `budget_frames`
+        frames (64 -> 308x588 per frame = cfg2's size at any clip length; 256 -> 140x280 = cfg3), scaled with the
+        shard so that every rank picks the same per-frame size."""
+        lo, hi = frame_shards(T_clip, world)[rank]
+        chunks = sorted({f // 64 for f in range(lo, hi)})
+        parts = {c: processing.synthetic_clip(64, kind=args.clip, clip_idx=c)[0] for c in chunks}
+        fr = np.stack([parts[f // 64][f % 64] for f in range(lo, hi)])
+        t0 = time.perf_counter()
+        dfr = torch.from_numpy(fr).to(dev)
+        torch.cuda.synchronize()
+        h2d = (time.perf_counter() - t0) * 1e3
+        ft = preprocess_videos_gpu([dfr], merge_size=2, max_tokens=16384 * (hi - lo) // budget_frames)
+        _, gh_, gw_ = (int(v) for v in ft["grid_sizes"][0])
+        return {"frames": fr, "dframes": dfr, "pix": ft["pixel_values"], "gh": gh_, "gw": gw_, "t_loc": hi - lo,
+                "grid_loc": torch.tensor([[hi - lo, gh_, gw_]]), "h2d_ms": h2d, "T": T_clip}
+
+    main_clip = make_clip(T, 256 if cfg3 else 64)
+    frames, dframes, h2d_ms = main_clip["frames"], main_clip["dframes"], main_clip["h2d_ms"]
+    pix = main_clip["pix"]        # bf16 on the GPU (evaluate/answer_generate.py:70 casts pixel_values to bf16)
+    gh, gw, t_loc, grid_loc = main_clip["gh"], main_clip["gw"], main_clip["t_loc"], main_clip["grid_loc"]
     per_frame = gh * gw
     P = per_frame // 4
     n_patches, m_tokens = T * per_frame, T * P
@@ -140,7 +158,7 @@ def main() -> None:
     pix_all = None
     if world == 1:
         t0 = time.perf_counter()
-        host = processing.preprocess_videos([frames], merge_size=2)
+        host = processing.preprocess_videos([frames], merge_size=2, max_tokens=16384 * t_loc // (256 if cfg3 else 64))
         t_host_pre = time.perf_counter() - t0
         pix_all = torch.from_numpy(host["pixel_values"])
         same_as_host = bool(torch.equal(pix.cpu(), pix_all.bfloat16()))
@@ -179,9 +197,10 @@ def main() -> None:
         "metric": "frames/sec encoded + answer tokens/sec, 64-frame clip, VideoLLaMA3-7B",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
+        "scaling": "strong" if (cfg3 or (world > 1 and not weak)) else "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{'cfg2' if T == 64 else 'cfg3-style'}: {T}x480x854 '{args.clip}' clip -> {gh * 14}x{gw * 14}, "
+        "config": {"workload": f"{'cfg3 (BASELINE configs[2])' if cfg3 else ('cfg2 (BASELINE configs[1])' if T == 64 else 'cfg2-sized frames')}: "
+                               f"{T}x480x854 '{args.clip}' clip -> {gh * 14}x{gw * 14}, "
                                f"{n_patches} patches, {m_tokens} visual tokens; ViT(1152x27, hd72)+projector(3584); "
                                f"random-init weights",
                    "frames": T, "frames_per_gpu": t_loc, "patches": n_patches, "visual_tokens": m_tokens,
@@ -203,17 +222,21 @@ def main() -> None:
         gflops = vit_gemm_flops(n_loc, m_proj, vcfg, lcfg.hidden_size)
         gemm_ms, gemm_n = float(ms[0]), int(cnt[0])
         ach = gflops / (gemm_ms * 1e-3) / 1e12
-        # HBM-side traffic per GEMM launch: PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 read
-        # correction) collected with tools/collect_profiles.sh and committed under profiles/
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_g_gemm_traffic.json")
-        if world == 1 and T == 64 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")
+        # HBM-side traffic per GEMM launch: NOT measured by this process (counters need their own rocprofv3 --pmc
+        # passes: FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction). The figure is read from the
+        # PMC summary of the same command committed under profiles/ (tools/collect_profiles.sh), and labelled so.
+        traffic, traffic_src = None, None
+        for name in ("r2_gemm_traffic.json", "r1_g_gemm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if world == 1 and T == 64 and not cfg3 and os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")
+                traffic_src = f"committed PMC profile profiles/{name} (separate rocprofv3 --pmc passes of this command), not this run"
+                break
         out["roofline"] = {"bound": "mfma",
                            "kernel": "bf16 MFMA GEMM (gemm_tn_pp_kernel<*> + gemm_tn_256x128_kernel<*>: every encoder+"
                                      "projector GEMM kernel of one step; a round-aligned split counts as two launches)",
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                            "flop_per_launch": gflops / max(gemm_n, 1)}
         attn_ms = float(ms[1])
@@ -222,6 +245,37 @@ def main() -> None:
         out["attention_tflops"] = round(vit_attn_flops(t_loc, per_frame, vcfg) / (attn_ms * 1e-3) / 1e12, 1)
         total_flops = vit_gemm_flops(n_patches, m_tokens, vcfg, lcfg.hidden_size) + vit_attn_flops(T, per_frame, vcfg)
         out["encoder_tflops"] = round(total_flops / (ms_per_step * 1e-3) / 1e12, 1)   # whole job, all GPUs
+
+    # ---- BASELINE configs[2] riding along: one 256-frame clip at the 16384-token budget, frames sharded over the
+    # ranks (32 per GPU at N = 8), one all-gather; every rank takes part, rank 0 reports ----
+    if not cfg3 and not args.no_cfg3 and 256 % world == 0 and args.frames == 64:
+        c3 = make_clip(256, 256)
+        g3 = (256, c3["gh"], c3["gw"])
+
+        def step3():
+            return gather_tokens(proj(enc(c3["pix"], c3["grid_loc"], merge)), g3, 2, world)
+
+        step3()
+        barrier()
+        n3 = max(3, min(args.steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(n3):
+            mm3 = step3()
+        barrier()
+        dt3 = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt3 = float(tt)
+        pf3 = c3["gh"] * c3["gw"]
+        if rank == 0:
+            fl3 = vit_gemm_flops(256 * pf3, 64 * pf3, vcfg, lcfg.hidden_size) + vit_attn_flops(256, pf3, vcfg)
+            out["cfg3"] = {"workload": f"BASELINE configs[2]: 256x480x854 '{args.clip}' clip -> {c3['gh'] * 14}x{c3['gw'] * 14}, "
+                                       f"{256 * pf3} patches, {64 * pf3} visual tokens, {c3['t_loc']} frames per GPU, one all-gather",
+                           "value": round(256 * n3 / dt3, 2), "unit": "frames/s", "ms_per_step": round(dt3 / n3 * 1e3, 3),
+                           "steps": n3, "scaling": "strong", "n_gpus": world, "frames_per_gpu": c3["t_loc"],
+                           "encoder_tflops": round(fl3 / (dt3 / n3) / 1e12, 1)}
+        del c3, mm3
 
     # ---- Qwen2-7B: prefill of the interleaved prompt + greedy decode (rank 0; other ranks wait) ----
     if rank == 0 and world == 1 and not args.no_llm:
@@ -260,6 +314,18 @@ def main() -> None:
                           (2.0 * S * 6.526e9 + 2.0 * S * S * lcfg.hidden_size * lcfg.num_hidden_layers / 2) / t_prefill / 1e12, 1),
                       "decode_hbm_gbps": round((len(toks) - 1) * (2 * 7.07e9 + 57344.0 * S) / t_dec / 1e9, 1)}
         out["e2e_s"] = round(ms_per_step * 1e-3 + t_gen, 4)
+        # the reference's SHIPPED generation mode (model/generation_config.json:2-12: do_sample, temperature 0.7,
+        # top_k 20, top_p 0.8, repetition_penalty 1.05), sampled on the device (cogs_sample, Philox draws)
+        cache.reset(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks_s = eng.generate(embeds, max_new_tokens=ndec, do_sample=True, temperature=0.7, top_k=20, top_p=0.8,
+                              repetition_penalty=1.05, ignore_eos=True, cache=cache, seed=1234)
+        torch.cuda.synchronize()
+        t_dec_s = max(time.perf_counter() - t0 - t_prefill, 1e-9)
+        out["answer_tokens_per_s_sampled"] = round((len(toks_s) - 1) / t_dec_s, 2)
+        out["llm"]["sampled"] = {"config": "do_sample T=0.7 top_k=20 top_p=0.8 repetition_penalty=1.05 (generation_config.json)",
+                                 "decode_tokens": len(toks_s), "decode_s": round(t_dec_s, 4), "sampler": "device (cogs_sample, Philox)"}
         del eng, cache
         torch.cuda.empty_cache()
 
