@@ -120,7 +120,10 @@ def test_cfg2_full_pipeline_with_real_token_ids(dev, model7b):
     enc, proj, eng, lcfg = model7b
     tok = ReplayTokenizer()
     model = CogReasoner(enc, proj, eng, lcfg)                       # DEFAULT_GENERATION = generation_config.json
-    frames, ts = pr.synthetic_clip(64, kind="drift", clip_idx=0)
+    base, ts = pr.synthetic_clip(64, kind="noise", clip_idx=0)
+    frames = np.repeat(base[:1], 64, axis=0)                       # static background (no sensor noise) ...
+    for i in range(64):                                            # ... and a 160 x 160 textured square moving 8 px per frame
+        frames[i, 160:320, 8 * i:8 * i + 160] = base[1, 160:320, :160]
     conv = [{"role": "user", "content": [{"type": "video", "video": frames, "timestamps": ts},
                                          {"type": "text", "text": "What is happening in the video?"}]}]
     inputs = pr.CogStreamProcessor(tok, device=dev)(conversation=conv)
