@@ -609,6 +609,11 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
     p.q_pos0 = a.q_pos0; p.causal = a.causal;
     const int nseg = a.cu_seqlens ? a.nseg : 1;
     p.nsplit = 1; p.gqa_pack = 0; p.q_prescaled = 0; p.part_o = nullptr; p.part_ml = nullptr;
+    // the encoder's production shape (per-frame segments, hd 72, pre-scaled Q, no masks) has its own kernel
+    static const bool env_old_vit = getenv("COGS_ATTN_VIT") && atoi(getenv("COGS_ATTN_VIT")) == 0;   // A/B runs only
+    if (a.dtype == COGS_DT_BF16 && !a.force_rowwise && a.head_dim == 72 && a.q_prescaled && a.cu_seqlens && !a.row_lo &&
+        !a.causal && a.nsplit <= 1 && a.hq == a.hkv && a.ldo % 8 == 0 && !env_old_vit)
+        return cogs_k_attention_vit(st, a);
     if (a.dtype == COGS_DT_BF16 && !a.force_rowwise && (a.head_dim == 72 || a.head_dim == 128)) {
         if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) return COGS_E_INVALID;
         const int max_len = a.cu_seqlens ? a.max_seqlen : a.q_len;
