@@ -40,14 +40,6 @@ struct VitAttnArgs {
 
 constexpr float RESCALE_THR = 6.0f;
 
-// sources of the LDS-DMA pad chunks: [0..3] = bf16 {1, 0 x7} (column HD of K and V), [4..7] = zeros
-__device__ __attribute__((aligned(16))) const unsigned int g_vit_pad[8] = {0x00003f80u, 0, 0, 0, 0, 0, 0, 0};
-
-__device__ __forceinline__ void vit_glds16(const char* g, char* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-
 #ifdef COGS_ATTN_STAMPS   // diagnostic build (tools/micro/attn_vit_micro.cpp): where does a tile's time go, wave 0 of workgroup 0
 __device__ unsigned long long g_attn_stamps[8];
 #define STAMP(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - st_prev; st_prev = now_; } while (0)
@@ -57,9 +49,9 @@ __device__ unsigned long long g_attn_stamps[8];
 
 __device__ __forceinline__ float bf16_round(float x) { return bf2f(f2bf(x)); }
 
-template <int HD, int WPS, int NW>
-__global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
-    constexpr int NT = 64 * NW, QB = 32 * NW;      // threads and query rows per workgroup
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
+    constexpr int NT = 256, QB = 128;               // threads and query rows per workgroup
     static_assert(HD % 8 == 0 && HD % 16 == 8 && HD < 96, "pad column HD must open a fresh 16-byte chunk inside the last k-step");
     constexpr int KS = (HD + 8) / 16;          // QK^T k-steps of 16 (72 -> 5: columns 0..79, column HD = the shift slot)
     constexpr int DB = (HD + 8 + 31) / 32;     // PV d-blocks of 32 (72 -> 3: rows 0..95 of O^T, row HD = the denominator)
@@ -129,9 +121,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
     const int l_off_k0 = st_row0 * KRS + st_c * 16;
     const int l_off_v0 = KT + st_row0 * VRS + st_c * 16;
     u32x4 kreg[PER], vreg[PER];
-    // staging is issued in four separate pieces spread over a tile's compute (K write + K load behind the QK^T MFMAs, V write
-    // + V load behind the softmax): issued in one burst right after the barrier the 4 waves' 24 loads queued up in the
-    // CU's vector-memory path for ~700 cycles per tile (in-kernel stamps)
+    // (measured and dropped, tools/micro + DESIGN.md section 8: the same pieces spread over the tile's compute phases,
+    // LDS-DMA instead of register staging, 8-wave workgroups, dedicated loader waves with a 3-deep LDS ring)
     auto load_k = [&](int t) {
         const int kbase = qs + t * 64;
         const int valid = min(64, qe - kbase);           // rows past the frame are zero filled (never read out of range)
@@ -163,41 +154,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
             if (st_row0 + RSTEP * i < 64) *reinterpret_cast<u32x4*>(buf + l_off_v0 + RSTEP * i * VRS) = vreg[i];
     };
 
-#ifdef COGS_ATTN_DMA
-    // LDS-DMA staging: a tile buffer is 23 pieces of 1 KiB (11 of K rows x 176 B, 12 of V rows x 192 B); a piece is one
-    // global_load_lds_dwordx4 per wave (LDS address = piece base + 16 * lane, the SOURCE address is per lane: data chunks
-    // from K / V, pad chunks from g_vit_pad). Wave w issues pieces w, w + 4, ... No staging registers, no ds_write.
-    constexpr int NPIECE = (KT + VT) / 1024;
-    constexpr int PPW = (NPIECE + 3) / 4;
-    int dma_off[PPW];      // >= 0: byte offset of the lane's chunk inside the 64-row tile of its operand; -1: pad "one"; -2: zero
-    int dma_row[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int pc = wid + 4 * i;
-        const bool isk = pc < KT / 1024;
-        const int ci = (isk ? pc : pc - KT / 1024) * 64 + lane;
-        const int per = isk ? KRS / 16 : VRS / 16;
-        const int row = ci / per, c = ci % per;
-        dma_row[i] = row;
-        dma_off[i] = c < CH ? (row * (int)(isk ? p.ldk : p.ldv) + head * HD + c * 8) * 2 : (c == CH ? -1 : -2);
-    }
-    auto dma_tile = [&](int t, char* buf) {
-        const int kbase = qs + t * 64;
-        const int valid = qe - kbase;
-        const char* kb = reinterpret_cast<const char*>(p.K + (long)kbase * p.ldk);
-        const char* vb = reinterpret_cast<const char*>(p.V + (long)kbase * p.ldv);
-        const char* pad = reinterpret_cast<const char*>(g_vit_pad);
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int pc = wid + 4 * i;
-            if (pc >= NPIECE) continue;                       // wave-uniform
-            const char* src = (pc < KT / 1024 ? kb : vb) + dma_off[i];
-            if (dma_off[i] < 0 || dma_row[i] >= valid) src = pad + (dma_off[i] == -1 ? 0 : 16);
-            vit_glds16(src, buf + pc * 1024);
-        }
-    };
-#endif
-
     // per-lane LDS read offsets
     const int k_rd = r32 * KRS + h * 16;                                              // + kb*32*KRS + s*32
     const int v_rd = KT + (4 * h + ((lane & 15) >> 2)) * VRS + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
@@ -213,21 +169,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
 #ifdef COGS_ATTN_STAMPS
     unsigned long long st_bar = 0, st_stage = 0, st_qk = 0, st_sm = 0, st_pv = 0, st_prev = __builtin_amdgcn_s_memtime();
 #endif
-#ifdef COGS_ATTN_DMA
-    dma_tile(0, smem);
-#else
     load_k(0); load_v(0);
     write_k(smem); write_v(smem);
     if (nt > 1) { load_k(1); load_v(1); }
-#endif
     // The Q loads must be seen as COMPLETE before the loop: otherwise hipcc's wait insertion puts an `s_waitcnt
     // vmcnt(0)` in front of the first QK^T MFMA of every tile (the loop header merges "Q may be in flight"), and that
     // wait also drains the K/V loads issued a moment earlier for tile t+2 -- the whole prefetch would be serialised.
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));
 
-    auto compute = [&](const char* buf, const int kbase, auto masked_tag, const int t_stage) {
-        // t_stage >= 0: tile t_stage + 1 is written to the other buffer and tile t_stage + 2 loaded, in pieces (see above)
+    auto compute = [&](const char* buf, const int kbase, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const int valid = qe - kbase;                                  // MASKED: keys >= valid do not exist
         const bool two = !MASKED || valid > 32;                        // wave-uniform: second 32-key block present
@@ -263,12 +214,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
                     }
             }
         };
-#ifdef COGS_ATTN_SPREAD
-        if (t_stage >= 0 && t_stage + 1 < nt) {
-            write_k(smem + ((t_stage + 1) & 1) * BUF);
-            if (t_stage + 2 < nt) load_k(t_stage + 2);
-        }
-#endif
         qk();
         STAMP(st_qk);
         // V^T fragments of d-block 0, issued before the softmax so that their LDS latency hides under it
@@ -280,12 +225,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
             return u32x4{l2[0], l2[1], h2[0], h2[1]};
         };
         u32x4 vf0[2][2];
-#ifndef COGS_ATTN_NO_VF0
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) vf0[kb][s2] = (MASKED && kb == 1 && !two) ? u32x4{0, 0, 0, 0} : read_v(0, kb, s2);
-#endif
         // row maximum relative to the reference: own 32 keys, then the partner half of the lane pair
         float d = sc[0][0];
 #pragma unroll
@@ -326,12 +269,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
                 for (int w = 0; w < 4; ++w)
                     pf[kb][s2][w] = pack_bf2(__builtin_amdgcn_exp2f(sc[kb][8 * s2 + 2 * w]),
                                              __builtin_amdgcn_exp2f(sc[kb][8 * s2 + 2 * w + 1]));
-#ifdef COGS_ATTN_SPREAD
-        if (t_stage >= 0 && t_stage + 1 < nt) {
-            write_v(smem + ((t_stage + 1) & 1) * BUF);
-            if (t_stage + 2 < nt) load_v(t_stage + 2);
-        }
-#endif
 #ifdef COGS_ATTN_STAMPS
         asm volatile("" :: "v"(pf[1][1]));
 #endif
@@ -344,11 +281,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
                 if (MASKED && kb == 1 && !two) continue;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-#ifndef COGS_ATTN_NO_VF0
                     const u32x4 w = b == 0 ? vf0[kb][s2] : read_v(b, kb, s2);
-#else
-                    const u32x4 w = read_v(b, kb, s2);
-#endif
                     oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, pf[kb][s2]),
                                                                      oacc[b], 0, 0, 0);
                 }
@@ -363,11 +296,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
         STAMP(st_pv);
         __syncthreads();                        // tile t is in buffer t&1; everyone is done with buffer (t+1)&1
         STAMP(st_bar);
-#ifdef COGS_ATTN_DMA
-        if (t + 1 < nt) dma_tile(t + 1, smem + ((t + 1) & 1) * BUF);
-        STAMP(st_stage);
-        if (wave_active) compute(smem + (t & 1) * BUF, qs + t * 64, std::false_type{}, -1);
-#elif !defined(COGS_ATTN_SPREAD)
         if (t + 1 < nt) {
 #ifndef ABL_NOWRITE
             write_k(smem + ((t + 1) & 1) * BUF); write_v(smem + ((t + 1) & 1) * BUF);
@@ -378,15 +306,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
         }
         STAMP(st_stage);
 #ifndef ABL_NOCOMPUTE
-        if (wave_active) compute(smem + (t & 1) * BUF, qs + t * 64, std::false_type{}, t);   // else: only stage and synchronise
-#endif
-#else
-        if (wave_active) {
-            compute(smem + (t & 1) * BUF, qs + t * 64, std::false_type{}, t);
-        } else if (t + 1 < nt) {                // a wave past the frame end only stages and synchronises
-            write_k(smem + ((t + 1) & 1) * BUF); write_v(smem + ((t + 1) & 1) * BUF);
-            if (t + 2 < nt) { load_k(t + 2); load_v(t + 2); }
-        }
+        if (wave_active) compute(smem + (t & 1) * BUF, qs + t * 64, std::false_type{});   // else: only stage and synchronise
 #endif
     }
 #ifdef COGS_ATTN_STAMPS
@@ -397,7 +317,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
 #endif
     if (full_tiles < nt) {
         __syncthreads();
-        if (wave_active) compute(smem + (full_tiles & 1) * BUF, qs + full_tiles * 64, std::true_type{}, -1);
+        if (wave_active) compute(smem + (full_tiles & 1) * BUF, qs + full_tiles * 64, std::true_type{});
     }
     if (!wave_active) return;
 
@@ -429,6 +349,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void attn_vit_kernel(VitAttnArgs p) {
     }
 }
 
+
 }  // namespace
 
 // block-diagonal bf16 attention with pre-scaled Q, hd 72, hq == hkv
@@ -439,18 +360,9 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     p.Q = (const bf16_t*)a.Q; p.K = (const bf16_t*)a.K; p.V = (const bf16_t*)a.V; p.O = (bf16_t*)a.O;
     p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo;
     p.cu = a.cu_seqlens;
-#ifndef COGS_ATTN_NW
-#define COGS_ATTN_NW 4
-#endif
-    constexpr int NW = COGS_ATTN_NW;
-    p.nseg = a.nseg; p.heads = a.hq; p.nqb = (a.max_seqlen + 32 * NW - 1) / (32 * NW);
+    p.nseg = a.nseg; p.heads = a.hq; p.nqb = (a.max_seqlen + 127) / 128;
     if ((long)p.nseg * p.heads * p.nqb > 0x7fffffffL) return COGS_E_INVALID;
     dim3 grid(p.nseg * p.heads * p.nqb);
-#ifndef COGS_ATTN_DEFAULT_WPS
-#define COGS_ATTN_DEFAULT_WPS 2
-#endif
-    static const int env_wps = getenv("COGS_ATTN_WPS") ? atoi(getenv("COGS_ATTN_WPS")) : COGS_ATTN_DEFAULT_WPS;   // tuning runs
-    if (env_wps == 3 && NW == 4) hipLaunchKernelGGL((attn_vit_kernel<72, 3, 4>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_vit_kernel<72, 2, NW>), grid, dim3(64 * NW), 0, st, p);
+    hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p);
     return COGS_LAUNCH_CHECK();
 }
