@@ -48,6 +48,10 @@ class GemmDesc(C.Structure):
         ("rope_lut", c_void_p),
         ("rope_rowpos", c_void_p),
         ("rope_maxpos", c_int),
+        ("row_stats", c_void_p),
+        ("ln_ab", c_void_p),
+        ("col_s", c_void_p),
+        ("col_c", c_void_p),
     ]
 
 
@@ -70,7 +74,8 @@ class AttnDesc(C.Structure):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, c_void_p) for n in (
-        "ln1_g", "ln1_b", "qkv_w", "qkv_b", "o_w", "o_b", "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+        "ln1_g", "ln1_b", "qkv_w", "qkv_b", "o_w", "o_b", "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+        "qkv_s", "qkv_c", "fc1_s", "fc1_c")]
 
 
 class VitWeights(C.Structure):
@@ -117,6 +122,7 @@ SIGNATURES = {
     "cogs_profile_begin": (c_int, [c_void_p]),
     "cogs_profile_end": (c_int, [c_void_p, c_void_p, C.POINTER(c_float), C.POINTER(c_int)]),
     "cogs_gemm": (c_int, [c_void_p, C.POINTER(GemmDesc)]),
+    "cogs_ln_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "cogs_attention": (c_int, [c_void_p, C.POINTER(AttnDesc)]),
     "cogs_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
     "cogs_rmsnorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),

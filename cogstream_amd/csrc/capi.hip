@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -122,6 +123,7 @@ CogsGemm to_gemm(const cogs_gemm_desc* d) {
     g.M = d->M; g.N = d->N; g.K = d->K; g.act = d->act; g.out_f32 = d->out_f32;
     g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.rope_cols = d->rope_cols; g.head_dim = d->head_dim;
     g.rope_lut = d->rope_lut; g.rope_rowpos = d->rope_rowpos; g.rope_maxpos = d->rope_maxpos;
+    g.row_stats = d->row_stats; g.ln_ab = d->ln_ab; g.col_s = d->col_s; g.col_c = d->col_c;
     return g;
 }
 
@@ -191,7 +193,13 @@ cogs_status cogs_destroy(cogs_handle h) {
 
 cogs_status cogs_gemm(cogs_stream stream, const cogs_gemm_desc* d) {
     if (!d || !d->A || !d->W || !d->C) return COGS_E_INVALID;
+    if (d->ln_ab && d->bias) return COGS_E_INVALID;     // col_c already contains the bias
     return cogs_k_gemm((hipStream_t)stream, to_gemm(d));
+}
+
+cogs_status cogs_ln_finalize(cogs_stream stream, const float* row_stats, int rows, int H, float eps, float* ln_ab) {
+    if (!row_stats || !ln_ab || rows <= 0 || H <= 0 || H % 64) return COGS_E_INVALID;
+    return cogs_k_ln_finalize((hipStream_t)stream, row_stats, rows, H / 64, H, eps, ln_ab);
 }
 
 cogs_status cogs_attention(cogs_stream stream, const cogs_attn_desc* d) {
@@ -386,6 +394,15 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
     if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
     char* qkv = (char*)big;
     char* att = qkv + (size_t)N * 3 * H * es;
+    // LayerNorm folded into the GEMMs (bf16 production path, cogs_vit_layer.qkv_s ...): the buffer that would hold LN(x)
+    // carries the per-row partial statistics [N][H/64][2] and the per-row (rstd, -rstd*mean) [N][2] instead
+    bool fold = dt == COGS_DT_BF16 && H % 64 == 0;
+    for (int l = 0; l < w.layers && fold; ++l) {
+        const cogs_vit_layer& L = h->vit_layers[l];
+        fold = L.qkv_s && L.qkv_c && L.fc1_s && L.fc1_c;
+    }
+    float* stat_part = (float*)ln;
+    float* ln_ab = stat_part + (size_t)N * (H / 64) * 2;
 
     // rotary position LUT for the ping-pong QKV GEMM (bf16, block-diagonal): (cos, sin)[pos][freq], kept in LDS there
     int maxpos = 0;
@@ -428,6 +445,7 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
         CogsGemm g; g.dtype = dt;
         g.A = xpad; g.lda = w.patch_pad; g.W = w.patch_w; g.ldw = w.patch_pad; g.C = x; g.ldc = H;
         g.bias = w.patch_b; g.M = (int)N; g.N = H; g.K = w.patch_pad;
+        if (fold) g.row_stats = stat_part;
         { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
     }
     const float scale = 1.0f / sqrtf((float)hd);
@@ -437,11 +455,14 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
     const bool prescale_q = dt == COGS_DT_BF16 && attn_mode == COGS_ATTN_BLOCK_DIAG && (hd == 72 || hd == 128);
     for (int l = 0; l < w.layers; ++l) {
         const cogs_vit_layer& L = h->vit_layers[l];
-        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln1_g, L.ln1_b, (int)N, H, w.ln_eps)); }
+        if (fold) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_ln_finalize(st, stat_part, (int)N, H / 64, H, w.ln_eps, ln_ab)); }
+        else { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln1_g, L.ln1_b, (int)N, H, w.ln_eps)); }
         {
             CogsGemm g; g.dtype = dt;
-            g.A = ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = 3 * H;
-            g.bias = L.qkv_b; g.M = (int)N; g.N = 3 * H; g.K = H;
+            g.A = fold ? x : ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = 3 * H;
+            g.M = (int)N; g.N = 3 * H; g.K = H;
+            if (fold) { g.ln_ab = ln_ab; g.col_s = L.qkv_s; g.col_c = L.qkv_c; }
+            else g.bias = L.qkv_b;
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = 2 * H; g.head_dim = hd;
             if (prescale_q) { g.q_scale = scale * 1.4426950408889634f; g.q_cols = H; }
             if (use_lut) { g.rope_lut = lut; g.rope_rowpos = lo; g.rope_maxpos = maxpos; }
@@ -461,19 +482,24 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
             CogsGemm g; g.dtype = dt;
             g.A = att; g.lda = H; g.W = L.o_w; g.ldw = H; g.C = x; g.ldc = H;
             g.bias = L.o_b; g.residual = x; g.ldr = H; g.M = (int)N; g.N = H; g.K = H;
+            if (fold) g.row_stats = stat_part;
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
-        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln2_g, L.ln2_b, (int)N, H, w.ln_eps)); }
+        if (fold) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_ln_finalize(st, stat_part, (int)N, H / 64, H, w.ln_eps, ln_ab)); }
+        else { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln2_g, L.ln2_b, (int)N, H, w.ln_eps)); }
         {
             CogsGemm g; g.dtype = dt;
-            g.A = ln; g.lda = H; g.W = L.fc1_w; g.ldw = H; g.C = big; g.ldc = w.inter_pad;
-            g.bias = L.fc1_b; g.M = (int)N; g.N = w.inter_pad; g.K = H; g.act = COGS_ACT_GELU_TANH;
+            g.A = fold ? x : ln; g.lda = H; g.W = L.fc1_w; g.ldw = H; g.C = big; g.ldc = w.inter_pad;
+            g.M = (int)N; g.N = w.inter_pad; g.K = H; g.act = COGS_ACT_GELU_TANH;
+            if (fold) { g.ln_ab = ln_ab; g.col_s = L.fc1_s; g.col_c = L.fc1_c; }
+            else g.bias = L.fc1_b;
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         {
             CogsGemm g; g.dtype = dt;
             g.A = big; g.lda = w.inter_pad; g.W = L.fc2_w; g.ldw = w.inter_pad; g.C = x; g.ldc = H;
             g.bias = L.fc2_b; g.residual = x; g.ldr = H; g.M = (int)N; g.N = H; g.K = w.inter_pad;
+            if (fold && l + 1 < w.layers) g.row_stats = stat_part;     // the last layer feeds post_layernorm (own kernel)
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
     }

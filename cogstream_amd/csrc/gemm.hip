@@ -486,8 +486,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
         // epilogue reports which of its two compile-time counts applies. A generic switch over the count costs
         // ~200 scalar cycles per K-tile -- measured slower than not relaxing at all.)
         if (PAIR_OK && epi_ops != 0 && kt < DIST3 - 1 && ahead >= DIST3) {
-            if (epi_ops == OPS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DIST3 - 1) + OPS_A) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DIST3 - 1) + OPS_B) : "memory");
+            // (the counter has 6 bits: a count clamped to 63 only waits for a few more operations than necessary)
+            constexpr int WAIT_A = 4 * (DIST3 - 1) + OPS_A < 63 ? 4 * (DIST3 - 1) + OPS_A : 63;
+            constexpr int WAIT_B = 4 * (DIST3 - 1) + OPS_B < 63 ? 4 * (DIST3 - 1) + OPS_B : 63;
+            if (epi_ops == OPS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_A) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_B) : "memory");
             return;
         }
         const int newer = (ahead < DIST3 ? ahead : DIST3) - 1;
@@ -673,6 +676,12 @@ void dispatch_pp(hipStream_t st, const GemmArgs& p, int grid, int mask) {
         COGS_PP_CASE(EPI_BIAS | EPI_ROPE | EPI_ROPE_LUT)
         COGS_PP_CASE(EPI_BIAS | EPI_GELU_TANH)
         COGS_PP_CASE(EPI_BIAS | EPI_GELU_ERF)
+        COGS_PP_CASE(EPI_BIAS | EPI_ROWSTAT)
+        COGS_PP_CASE(EPI_BIAS | EPI_RES | EPI_ROWSTAT)
+        COGS_PP_CASE(EPI_BIAS | EPI_LNFOLD)
+        COGS_PP_CASE(EPI_BIAS | EPI_ROPE | EPI_LNFOLD)
+        COGS_PP_CASE(EPI_BIAS | EPI_ROPE | EPI_ROPE_LUT | EPI_LNFOLD)
+        COGS_PP_CASE(EPI_BIAS | EPI_GELU_TANH | EPI_LNFOLD)
         COGS_PP_CASE(EPI_SWIGLU)
         COGS_PP_CASE(EPI_F32OUT)
         COGS_PP_CASE(EPI_NOSTORE)
@@ -693,6 +702,11 @@ void dispatch(hipStream_t st, const GemmArgs& p, int grid, int mask, bool big) {
         COGS_EPI_CASE(EPI_BIAS | EPI_ROPE)
         COGS_EPI_CASE(EPI_BIAS | EPI_GELU_TANH)
         COGS_EPI_CASE(EPI_BIAS | EPI_GELU_ERF)
+        COGS_EPI_CASE(EPI_BIAS | EPI_ROWSTAT)
+        COGS_EPI_CASE(EPI_BIAS | EPI_RES | EPI_ROWSTAT)
+        COGS_EPI_CASE(EPI_BIAS | EPI_LNFOLD)
+        COGS_EPI_CASE(EPI_BIAS | EPI_ROPE | EPI_LNFOLD)
+        COGS_EPI_CASE(EPI_BIAS | EPI_GELU_TANH | EPI_LNFOLD)
         COGS_EPI_CASE(EPI_SWIGLU)
         COGS_EPI_CASE(EPI_F32OUT)
         default: if (big) launch_big<T, EPI_GENERIC>(st, p, grid); else launch_small<T, EPI_GENERIC>(st, p, grid); break;
@@ -735,7 +749,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         p.group_m = env_gm > 0 ? env_gm : ((p.nbn <= 6 && g.K >= 2048) ? 2 : GROUP_M);
         int pp_mask = cogs_epi_mask(g);
         p.rope_lut = nullptr; p.rope_lut_bytes = 0;
-        if (pp_mask == (EPI_BIAS | EPI_ROPE) && g.rope_lut && g.rope_rowpos && !g.rope_sin && !env_nolut) {
+        if ((pp_mask & ~EPI_LNFOLD) == (EPI_BIAS | EPI_ROPE) && g.rope_lut && g.rope_rowpos && !g.rope_sin && !env_nolut) {
             const int lut_bytes = g.rope_maxpos * (g.head_dim / 4) * 8;
             if (lut_bytes > 0 && lut_bytes <= 28 * 1024 && g.rope_maxpos < 65536) {
                 pp_mask |= EPI_ROPE_LUT;
@@ -763,6 +777,8 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
                 b.C = (char*)g.C + (size_t)rows_main * g.ldc * (g.out_f32 ? 4 : es);
                 if (g.residual) b.residual = (const char*)g.residual + (size_t)rows_main * g.ldr * es;
                 if (g.rope_rowpos) b.rope_rowpos = g.rope_rowpos + rows_main;
+                if (g.row_stats) b.row_stats = g.row_stats + (size_t)rows_main * (g.N / 64) * 2;
+                if (g.ln_ab) b.ln_ab = g.ln_ab + (size_t)rows_main * 2;
                 if (g.rope_cos) {
                     const size_t per_row = (size_t)(g.head_dim / 2) * (g.rope_sin ? 1 : 2);
                     b.rope_cos = g.rope_cos + (size_t)rows_main * per_row;

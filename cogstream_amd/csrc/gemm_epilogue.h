@@ -29,6 +29,18 @@
 #define EPI_GENERIC 128   // decide everything at run time (rare combinations)
 #define EPI_ROPE_LUT 512  // with EPI_ROPE, ping-pong kernel only: rotary factors from the LDS-resident position LUT
 #define EPI_NOSTORE 256   // diagnostics only (COGS_GEMM_NOSTORE): accumulators kept live, nothing written
+// LayerNorm fused around the GEMMs (model/modeling_videollama3_encoder.py:382-391: x += attn(LN1(x)); x += mlp(LN2(x))):
+//   EPI_ROWSTAT  the GEMM that PRODUCES the residual stream x (patch embed, out-proj, fc2; N = hidden) also writes, per
+//                row and 64-column wave tile, the partial sums (sum x, sum x^2) of its fp32 outputs: stat_part[M][N/64][2].
+//                A tiny kernel turns them into (a, b) = (rstd, -rstd * mean) per row (cogs_k_ln_finalize).
+//   EPI_LNFOLD   the GEMM that CONSUMES LN(x) reads x itself with W'' = rows of W * diag(gamma) CENTRED (their mean over k
+//                subtracted, folded at load time: sum_k x_k W''[n][k] = sum_k (x_k - mean) W'[n][k]) and applies
+//                y[r][n] = rstd_r * acc[r][n] + c_n, c_n = bias_n + sum_k beta_k W[n][k] -- algebraically LN(x) W^T + bias,
+//                with no normalised copy of x ever written or read and no extra arithmetic in the epilogue (the bias add
+//                becomes an fma). What is neglected: rstd * mean * (sum_k of the bf16 ROUNDING of W''), bounded by
+//                ~6e-4 * |mean / std| of the output scale at K = 1152.
+#define EPI_ROWSTAT 1024
+#define EPI_LNFOLD 2048
 
 struct EpiArgs {
     char* C; long ldc;          // elements per row
@@ -46,7 +58,22 @@ struct EpiArgs {
     int rope_maxpos;            //   positions in the LUT (LUT row = rope_pairs/2 frequencies x (cos, sin))
     float q_scale;              // != 1: columns < q_cols are multiplied by it after bias/rope, before the (single) rounding
     int q_cols;                 //   (the attention kernels then take Q pre-scaled by softmax_scale*log2(e))
+    float* stat_part;           // EPI_ROWSTAT: [M][stat_tiles][2] fp32
+    int stat_tiles;             //   = N / 64
+    const float* ln_ab;         // EPI_LNFOLD: [M][2] fp32 (rstd, -rstd * mean); the epilogues read rstd only (centred W)
+    const float* col_s;         //   unused by the kernels (kept in the descriptor for reference implementations)
+    const float* col_c;         //   [N] fp32 (replaces bias)
 };
+
+// sum over the four lanes {r, r+16, r+32, r+48} that share a row of a 16x16 accumulator tile, result in all four
+__device__ __forceinline__ float rowgroup_sum(float x) {
+    const unsigned xb = __builtin_bit_cast(unsigned, x);
+    const auto a = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
+    const float y = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned yb = __builtin_bit_cast(unsigned, y);
+    const auto b = __builtin_amdgcn_permlane32_swap(yb, yb, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
 
 // (cos, sin) of the two rotary pairs pi, pi+1 of row m, from either table format
 __device__ __forceinline__ void rope_load(const EpiArgs& p, long m, int pi, f32x2& c, f32x2& s) {
@@ -60,18 +87,25 @@ __device__ __forceinline__ void rope_load(const EpiArgs& p, long m, int pi, f32x
     }
 }
 
+// rotate the two pairs (v0, v1), (v2, v3) by (c0, s0), (c1, s1). ONE spelling with explicit fmaf for every epilogue: left
+// to -ffp-contract the compiler fuses `a*c - b*s` one way in one epilogue and the other way in the next, and a row that
+// takes the ragged-block epilogue in a frame-sharded encode then differs from the whole-clip encode in the last bit
+__device__ __forceinline__ f32x4 rope_rot(f32x4 v, float c0, float s0, float c1, float s1) {
+    f32x4 r;
+    r[0] = fmaf(-v[1], s0, v[0] * c0);
+    r[1] = fmaf(v[0], s0, v[1] * c0);
+    r[2] = fmaf(-v[3], s1, v[2] * c1);
+    r[3] = fmaf(v[2], s1, v[3] * c1);
+    return r;
+}
+
 template <typename T>
 __device__ __forceinline__ void epilogue4(const EpiArgs& p, int m, int n, f32x4 v) {
     if (p.bias) v += ld4_f<T>(reinterpret_cast<const T*>(p.bias) + n);
     if (p.rope_cos && n < p.rope_cols) {
         f32x2 c, s;
         rope_load(p, m, (n % p.head_dim) >> 1, c, s);
-        f32x4 r;
-        r[0] = v[0] * c[0] - v[1] * s[0];
-        r[1] = v[1] * c[0] + v[0] * s[0];
-        r[2] = v[2] * c[1] - v[3] * s[1];
-        r[3] = v[3] * c[1] + v[2] * s[1];
-        v = r;
+        v = rope_rot(v, c[0], s[0], c[1], s[1]);
     }
     if (n < p.q_cols) v *= p.q_scale;
     if (p.act == COGS_ACT_GELU_TANH) {
@@ -151,7 +185,10 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
         int nn[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) nn[i] = min(ncol + i * 16, N - 4);
-        if constexpr ((EPI & EPI_BIAS) != 0) {
+        if constexpr ((EPI & EPI_LNFOLD) != 0) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bias_v[ni] = *reinterpret_cast<const f32x4*>(p.col_c + nn[ni]);
+        } else if constexpr ((EPI & EPI_BIAS) != 0) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) bias_v[ni] = ld4_f<T>(reinterpret_cast<const T*>(p.bias) + nn[ni]);
         }
@@ -161,8 +198,13 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
             u32x4 res_wide[2][2];
             f32x2 cs[2][4], sn[2][4];
             int mm[2];
+            float rs2[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) mm[i] = min(mrow + (2 * half + i) * 16, M - 1);
+            if constexpr ((EPI & EPI_LNFOLD) != 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) rs2[i] = p.ln_ab[2 * (long)mm[i]];
+            }
             if constexpr ((EPI & EPI_RES) != 0) {
                 if (wide) {
                     if constexpr (CAN_WIDE) {
@@ -194,20 +236,19 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
                 const int mi = 2 * half + i;
                 const int m = mrow + mi * 16;
                 f32x4 v[4];
+                float st1 = 0.f, st2 = 0.f;   // EPI_ROWSTAT: this lane's share of (sum x, sum x^2) of row m in this tile
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int n = ncol + ni * 16;
                     v[ni] = acc[mi][ni];
-                    if constexpr ((EPI & EPI_BIAS) != 0) v[ni] += bias_v[ni];
+                    if constexpr ((EPI & EPI_LNFOLD) != 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[ni][e] = fmaf(rs2[i], v[ni][e], bias_v[ni][e]);
+                    } else if constexpr ((EPI & EPI_BIAS) != 0) v[ni] += bias_v[ni];
                     if constexpr ((EPI & EPI_ROPE) != 0) {
                         if (n < p.rope_cols) {
                             const f32x2 c = cs[i][ni], sx = sn[i][ni];
-                            f32x4 r;
-                            r[0] = v[ni][0] * c[0] - v[ni][1] * sx[0];
-                            r[1] = v[ni][1] * c[0] + v[ni][0] * sx[0];
-                            r[2] = v[ni][2] * c[1] - v[ni][3] * sx[1];
-                            r[3] = v[ni][3] * c[1] + v[ni][2] * sx[1];
-                            v[ni] = r;
+                            v[ni] = rope_rot(v[ni], c[0], sx[0], c[1], sx[1]);
                         }
                         if (n < p.q_cols) v[ni] *= p.q_scale;
                     }
@@ -233,6 +274,20 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
                                 va += f32x4{bf_lo(x0[0]), bf_hi(x0[0]), bf_lo(x1[0]), bf_hi(x1[0])};
                                 vb += f32x4{bf_lo(x0[1]), bf_hi(x0[1]), bf_lo(x1[1]), bf_hi(x1[1])};
                             }
+                            if constexpr ((EPI & EPI_ROWSTAT) != 0) {
+                                // the SAME association as epilogue_pair_fast (a 32-column unit summed from zero, units added
+                                // in order): a row's statistics must not depend on which epilogue its tile happened to take,
+                                // or a frame-sharded encode would differ from the whole-clip encode in the last bit
+                                if (nb + 32 * pr < N) {
+                                    float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        u1 += va[e] + vb[e];
+                                        u2 = fmaf(va[e], va[e], fmaf(vb[e], vb[e], u2));
+                                    }
+                                    if (pr == 0) { st1 = u1; st2 = u2; } else { st1 += u1; st2 += u2; }
+                                }
+                            }
                             const unsigned a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]);
                             const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
                             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
@@ -247,6 +302,12 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
                     for (int ni = 0; ni < 4; ++ni) {
                         const int n = ncol + ni * 16;
                         if constexpr ((EPI & EPI_RES) != 0) v[ni] += RawVec<T>::to_f32(res_raw[i][ni]);
+                        if constexpr ((EPI & EPI_ROWSTAT) != 0) {
+                            if (n < N) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { st1 += v[ni][e]; st2 = fmaf(v[ni][e], v[ni][e], st2); }
+                            }
+                        }
                         if (m < M && n < N) {
                             if constexpr ((EPI & EPI_SWIGLU) != 0) {
                                 T* cp = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + (n >> 1);
@@ -259,6 +320,12 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
                             }
                         }
                     }
+                }
+                if constexpr ((EPI & EPI_ROWSTAT) != 0) {
+                    st1 = rowgroup_sum(st1);
+                    st2 = rowgroup_sum(st2);
+                    if (g4 == 0 && m < M && nb < N)
+                        *reinterpret_cast<f32x2*>(p.stat_part + ((long)m * p.stat_tiles + (nb >> 6)) * 2) = f32x2{st1, st2};
                 }
             }
         }
@@ -274,12 +341,6 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
 template <int EPI>
 __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int nb, int lane, f32x4 (&acc)[4][4]) {
     typedef bf16_t T;
-    // Region markers for the build-time check (cogstream_amd/build.py::check_epilogue_vmem_counts): the relaxed
-    // vmcnt of the ping-pong kernel's next-tile waits is only right if hipcc emits exactly epi_pair_vmem_ops<EPI>()
-    // vector-memory instructions between these two markers; the build disassembles gemm.o and counts them.
-    // s_nop 8 / 9 = begin (without / with rotary loads), s_nop 10 = end. ("memory": nothing moves across.)
-    if constexpr ((EPI & EPI_ROPE) != 0) asm volatile("s_nop 9" ::: "memory");
-    else asm volatile("s_nop 8" ::: "memory");
     const int r = lane & 15, g4 = lane >> 4;
     const int wcol = 16 * (g4 & 1) + 8 * (g4 >> 1);
     char* const cbase = p.C + ((long)mb * p.ldc + nb) * 2;
@@ -342,12 +403,7 @@ __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int
                 if constexpr ((EPI & EPI_BIAS) != 0) v[ni] += bias_v[ni];
                 if constexpr ((EPI & EPI_ROPE) != 0) {
                     const f32x4 t = cs4[i][ni];   // c0 s0 c1 s1
-                    f32x4 q;
-                    q[0] = v[ni][0] * t[0] - v[ni][1] * t[1];
-                    q[1] = v[ni][1] * t[0] + v[ni][0] * t[1];
-                    q[2] = v[ni][2] * t[2] - v[ni][3] * t[3];
-                    q[3] = v[ni][3] * t[2] + v[ni][2] * t[3];
-                    v[ni] = q;
+                    v[ni] = rope_rot(v[ni], t[0], t[1], t[2], t[3]);
                     if (q_tile) v[ni] *= p.q_scale;
                 }
                 if constexpr ((EPI & EPI_GELU_TANH) != 0) {
@@ -383,7 +439,7 @@ __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_wave(const EpiArgs& p, int mb, int nb, int M, int N, int lane,
                                               f32x4 (&acc)[4][4]) {
-    if constexpr (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0) {
+    if constexpr (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE | EPI_ROWSTAT | EPI_LNFOLD)) == 0) {
         bool fast = mb + 64 <= M && nb + 64 <= N && (N & 31) == 0 && (p.ldc & 7) == 0 &&
                     (reinterpret_cast<unsigned long>(p.C) & 15) == 0;
         if constexpr ((EPI & EPI_RES) != 0) fast = fast && (p.ldr & 7) == 0 && (reinterpret_cast<unsigned long>(p.R) & 15) == 0;
@@ -431,10 +487,27 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
         r_row16 = p.ldr * 32;
     }
     f32x4 bias_v[4];
-    if constexpr ((EPI & EPI_BIAS) != 0) {
+    if constexpr ((EPI & EPI_LNFOLD) != 0) {
+        // y = rstd_r * acc + c_n (W rows are centred, so the mean term vanishes): c takes the place of the bias (fp32)
+        const char* cbase2 = reinterpret_cast<const char*>(p.col_c) + (long)nb * 4;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bias_v[ni] = *reinterpret_cast<const f32x4*>(cbase2 + (unsigned)(g4 * 16 + ni * 64));
+    } else if constexpr ((EPI & EPI_BIAS) != 0) {
         const char* bbase = reinterpret_cast<const char*>(p.bias) + (long)nb * 2;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bias_v[ni] = ld4_f<T>(reinterpret_cast<const T*>(bbase + (unsigned)(g4 * 8 + ni * 32)));
+    }
+    // EPI_LNFOLD: rstd of row mb + 16 blk + r. Loaded with the batch that first touches the row block (one 4-byte load
+    // per row block, 8 per epilogue) into a ring indexed by blk & 7 for 4-unit batches (6 row blocks in flight) or
+    // blk & 1 for the rotary kernels' 1-unit batches (2 in flight): the rotary epilogue has no registers to spare
+    const char* rsbase = nullptr;
+    if constexpr ((EPI & EPI_LNFOLD) != 0) rsbase = reinterpret_cast<const char*>(p.ln_ab) + ((long)mb + r) * 8;
+    float rs_ring[8];
+    char* stbase = nullptr;            // EPI_ROWSTAT: partials of row mb + 16 blk + r, this wave tile
+    long st_row16 = 0;
+    if constexpr ((EPI & EPI_ROWSTAT) != 0) {
+        stbase = reinterpret_cast<char*>(p.stat_part) + (((long)mb + r) * p.stat_tiles + (nb >> 6)) * 8;
+        st_row16 = (long)p.stat_tiles * 128;
     }
     const bool q_tile = nb < p.q_cols;
     const char* csbase = nullptr;
@@ -479,10 +552,14 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
     constexpr int NB = 16 / UPB;
     u32x4 res_wide[NB][UPB];
     f32x4 cs4[NB][UPB][2];
+    float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};   // EPI_ROWSTAT: running sums of the batch's (<= 2) row blocks
     auto load_batch = [&](const int b) {
 #pragma unroll
         for (int j = 0; j < UPB; ++j) {
             const int u = UPB * b + j, blk = u >> 1, pr = u & 1;
+            if constexpr ((EPI & EPI_LNFOLD) != 0) {
+                if (pr == 0) rs_ring[UPB == 1 ? (blk & 1) : blk] = *reinterpret_cast<const float*>(rsbase + blk * 128);
+            }
             if constexpr ((EPI & EPI_RES) != 0)
                 res_wide[b][j] = *reinterpret_cast<const u32x4*>(rbase + blk * r_row16 + r_lane + 64 * pr);
             if constexpr ((EPI & EPI_ROPE) != 0) {
@@ -511,15 +588,14 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int ni = 2 * pr + h2;
                 v[h2] = (blk < 4) ? acc0[mi][ni] : acc1[mi][ni];
-                if constexpr ((EPI & EPI_BIAS) != 0) v[h2] += bias_v[ni];
+                if constexpr ((EPI & EPI_LNFOLD) != 0) {
+                    const float rs = rs_ring[UPB == 1 ? (blk & 1) : blk];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[h2][e] = fmaf(rs, v[h2][e], bias_v[ni][e]);
+                } else if constexpr ((EPI & EPI_BIAS) != 0) v[h2] += bias_v[ni];
                 if constexpr ((EPI & EPI_ROPE) != 0) {
                     const f32x4 t = cs4[b][j][h2];   // c0 s0 c1 s1
-                    f32x4 q;
-                    q[0] = v[h2][0] * t[0] - v[h2][1] * t[1];
-                    q[1] = v[h2][1] * t[0] + v[h2][0] * t[1];
-                    q[2] = v[h2][2] * t[2] - v[h2][3] * t[3];
-                    q[3] = v[h2][3] * t[2] + v[h2][2] * t[3];
-                    v[h2] = q;
+                    v[h2] = rope_rot(v[h2], t[0], t[1], t[2], t[3]);
                     if (q_tile) v[h2] *= p.q_scale;
                 }
                 if constexpr ((EPI & EPI_GELU_TANH) != 0) {
@@ -539,6 +615,17 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
                 va += f32x4{bf_lo(x0[0]), bf_hi(x0[0]), bf_lo(x1[0]), bf_hi(x1[0])};
                 vb += f32x4{bf_lo(x0[1]), bf_hi(x0[1]), bf_lo(x1[1]), bf_hi(x1[1])};
             }
+            if constexpr ((EPI & EPI_ROWSTAT) != 0) {
+                // row block blk of the batch = (j >> 1) (UPB == 4: units 4b..4b+3 = row blocks 2b, 2b+1, two units each)
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1 += va[e] + vb[e];
+                    s2 = fmaf(va[e], va[e], fmaf(vb[e], vb[e], s2));
+                }
+                if ((j & 1) == 0) { st_sum[j >> 1] = s1; st_sq[j >> 1] = s2; }
+                else { st_sum[j >> 1] += s1; st_sq[j >> 1] += s2; }
+            }
             const unsigned a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]);
             const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
@@ -552,8 +639,19 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
             const int u = UPB * b + j, blk = u >> 1, pr = u & 1;
             *reinterpret_cast<u32x4*>(cbase + blk * c_row16 + c_lane + 64 * pr) = outv[j];
         }
+        if constexpr ((EPI & EPI_ROWSTAT) != 0) {
+            static_assert((EPI & EPI_ROWSTAT) == 0 || UPB == 4, "row statistics are laid out for 4-unit batches");
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float t1 = rowgroup_sum(st_sum[k]), t2 = rowgroup_sum(st_sq[k]);
+                // all four lanes of a row hold the totals; ONE of them writes (8 bytes per row and wave tile). The store
+                // is issued by every lane with the other three pointed at the same address and value: no exec masking,
+                // so the instruction count the relaxed vmcnt relies on stays fixed (2 per batch, 8 per epilogue)
+                *reinterpret_cast<f32x2*>(stbase + (2 * b + k) * st_row16) = f32x2{t1, t2};
+            }
+        }
     };
-    constexpr bool HAS_LOADS = (EPI & (EPI_RES | EPI_ROPE)) != 0;
+    constexpr bool HAS_LOADS = (EPI & (EPI_RES | EPI_ROPE | EPI_LNFOLD)) != 0;
     if constexpr (HAS_LOADS) { load_batch(0); load_batch(1); }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -568,7 +666,8 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
 template <int EPI>
 constexpr int epi_pair_vmem_ops() {
     return 16 + ((EPI & EPI_BIAS) ? 4 : 0) + ((EPI & EPI_RES) ? 16 : 0) +
-           ((EPI & EPI_ROPE) ? ((EPI & EPI_ROPE_LUT) ? 8 : 32) : 0);
+           ((EPI & EPI_ROPE) ? ((EPI & EPI_ROPE_LUT) ? 8 : 32) : 0) + ((EPI & EPI_LNFOLD) ? 8 : 0) +
+           ((EPI & EPI_ROWSTAT) ? 8 : 0);
 }
 
 // Returns the number of vector-memory instructions issued when that is known exactly (pipelined path), else -1.
@@ -611,12 +710,18 @@ inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {
     e->head_dim = g.head_dim > 0 ? g.head_dim : 4;
     e->q_scale = g.q_scale; e->q_cols = g.q_scale != 1.f ? g.q_cols : 0;
     e->rope_rowpos = g.rope_rowpos; e->rope_lut_lds = 0; e->rope_maxpos = g.rope_maxpos;
+    e->stat_part = g.row_stats; e->stat_tiles = g.N / 64;
+    e->ln_ab = g.ln_ab; e->col_s = g.col_s; e->col_c = g.col_c;
+    if (g.row_stats && (g.N % 64 != 0 || g.out_f32 || g.act == COGS_ACT_SWIGLU)) return COGS_E_INVALID;
+    if (g.ln_ab && (!g.col_c || g.act == COGS_ACT_SWIGLU || g.N % 4 != 0)) return COGS_E_INVALID;
     return COGS_OK;
 }
 
 // the compile-time mask for a descriptor, or EPI_GENERIC when the combination has no specialisation
 inline int cogs_epi_mask(const CogsGemm& g) {
     int m = 0;
+    if (g.row_stats) m |= EPI_ROWSTAT;
+    if (g.ln_ab) m |= EPI_LNFOLD | EPI_BIAS;     // col_c plays the bias role
     if (g.bias) m |= EPI_BIAS;
     if (g.residual) m |= EPI_RES;
     if (g.rope_cos) m |= EPI_ROPE;
@@ -627,6 +732,8 @@ inline int cogs_epi_mask(const CogsGemm& g) {
     switch (m) {
         case 0: case EPI_BIAS: case EPI_RES: case EPI_BIAS | EPI_RES: case EPI_BIAS | EPI_ROPE:
         case EPI_BIAS | EPI_GELU_TANH: case EPI_BIAS | EPI_GELU_ERF: case EPI_SWIGLU: case EPI_F32OUT:
+        case EPI_BIAS | EPI_ROWSTAT: case EPI_BIAS | EPI_RES | EPI_ROWSTAT:
+        case EPI_BIAS | EPI_ROPE | EPI_LNFOLD: case EPI_BIAS | EPI_GELU_TANH | EPI_LNFOLD: case EPI_BIAS | EPI_LNFOLD:
             return m;
         default:
             return EPI_GENERIC;

@@ -86,6 +86,27 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
 #pragma unroll
     for (int r = 0; r < R; ++r) w[r] = reinterpret_cast<const T*>(p.W + (long)min(n + r, p.N - 1) * p.ldw);
     const T* gam = reinterpret_cast<const T*>(p.rms_gamma);
+    auto to_f = [](const u32x4& raw, float (&o)[EPC]) {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[2 * i] = bf_lo(raw[i]); o[2 * i + 1] = bf_hi(raw[i]); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(raw[i]);
+        }
+    };
+    // The first batch of weight chunks is requested BEFORE the fused RMSNorm statistics: the weights do not depend
+    // on x, and the statistics (a dependent load -> reduce -> rsqrt chain, ~2 us) would otherwise sit in front of the
+    // whole stream (the qkv GEMV took 14.8 us against 8.0 us for the o projection of nearly the same size).
+    int ch = lane;
+    u32x4 w_first[U][R];
+    const bool have_first = ch + 64 * (U - 1) < nch;
+    if (have_first) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) w_first[u][r] = *reinterpret_cast<const u32x4*>(w[r] + (ch + 64 * u) * EPC);
+    }
     float rstd = 1.f;
     if (gam) {
         // every wave covers the whole x with its 64 lanes: the statistics need no LDS and no barrier
@@ -100,19 +121,29 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
         ss = wave_sum(ss);
         rstd = rsqrtf(ss / (float)p.K + p.rms_eps);
     }
-    auto to_f = [](const u32x4& raw, float (&o)[EPC]) {
-        if constexpr (sizeof(T) == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { o[2 * i] = bf_lo(raw[i]); o[2 * i + 1] = bf_hi(raw[i]); }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(raw[i]);
-        }
-    };
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
-    int ch = lane;
+    if (have_first) {
+        u32x4 xr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xr[u] = *reinterpret_cast<const u32x4*>(x + (ch + 64 * u) * EPC);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float xa[EPC];
+            to_f(xr[u], xa);
+            if (gam) rms_apply<T, EPC>(xa, gam + (ch + 64 * u) * EPC, rstd);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float wa[EPC];
+                to_f(w_first[u][r], wa);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[r] += wa[e] * xa[e];
+            }
+        }
+        ch += 64 * U;
+    }
+
     for (; ch + 64 * (U - 1) < nch; ch += 64 * U) {
         u32x4 wr[U][R], xr[U];
 #pragma unroll

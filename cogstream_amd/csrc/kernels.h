@@ -37,8 +37,18 @@ struct CogsGemm {
     // [M] = h | w << 16. The ping-pong kernel keeps the LUT in LDS and reads the factors from there (first half of a
     // head's pairs rotates with h, second half with w); rope_cos must still be the matching per-row table.
     const float* rope_lut = nullptr; const int* rope_rowpos = nullptr; int rope_maxpos = 0;
+    // LayerNorm fused around the GEMM (gemm_epilogue.h EPI_ROWSTAT / EPI_LNFOLD; bf16 kernels):
+    float* row_stats = nullptr;              // != null: also write per-row partial (sum, sum of squares) of the outputs,
+                                             //   [M][N/64][2] fp32 (N % 64 == 0)
+    const float* ln_ab = nullptr;            // != null: y = ln_ab[r][0] * acc + (ln_ab[r][1] * col_s[n] + col_c[n]) instead of
+    const float* col_s = nullptr;            //   acc + bias (W carries gamma; col_c = bias + W.beta); bias must be null
+    const float* col_c = nullptr;
 };
 int cogs_k_gemm(hipStream_t st, const CogsGemm& g);
+// (a, b) = (rstd, -rstd * mean) per row from the EPI_ROWSTAT partials [rows][tiles][2]: ab [rows][2]
+int cogs_k_ln_finalize(hipStream_t st, const float* stat_part, int rows, int tiles, int H, float eps, float* ab);
+// (a, b) = (rstd, -rstd * mean) per row from the EPI_ROWSTAT partials: ab [rows][2]
+int cogs_k_ln_finalize(hipStream_t st, const float* stat_part, int rows, int tiles, int H, float eps, float* ab);
 
 struct CogsAttn {
     int dtype = 0;

@@ -188,6 +188,21 @@ int launch_ln_merge(hipStream_t st, const void* x, void* y, const void* g, const
     return COGS_LAUNCH_CHECK();
 }
 
+// (a, b) = (rstd, -rstd * mean) of every row from the per-tile partial sums the producing GEMM's epilogue wrote
+// (EPI_ROWSTAT): fixed-order fp64 combination, biased variance like nn.LayerNorm
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int rows, int tiles, float inv_h,
+                                                          float eps, float* __restrict__ ab) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const f32x2* p = reinterpret_cast<const f32x2*>(part) + (long)r * tiles;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < tiles; ++t) { const f32x2 v = p[t]; s1 += (double)v[0]; s2 += (double)v[1]; }
+    const double mean = s1 * inv_h;
+    const double var = fmax(s2 * inv_h - mean * mean, 0.0);
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    *reinterpret_cast<f32x2*>(ab + 2 * (long)r) = f32x2{rstd, (float)(-(double)rstd * mean)};
+}
+
 }  // namespace
 
 int cogs_k_layernorm(hipStream_t st, int dtype, const void* x, void* y, const void* gamma, const void* beta,
@@ -211,4 +226,11 @@ int cogs_k_ln_merge(hipStream_t st, int dtype, const void* x, void* y, const voi
     if (H % 8 || group <= 0) return COGS_E_INVALID;
     return dtype == COGS_DT_BF16 ? launch_ln_merge<bf16_t>(st, x, y, gamma, beta, out_rows, group, H, eps)
                                  : launch_ln_merge<float>(st, x, y, gamma, beta, out_rows, group, H, eps);
+}
+
+int cogs_k_ln_finalize(hipStream_t st, const float* stat_part, int rows, int tiles, int H, float eps, float* ab) {
+    if (rows <= 0 || tiles <= 0 || H <= 0) return COGS_E_INVALID;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, stat_part, rows, tiles, 1.0f / (float)H,
+                       eps, ab);
+    return COGS_LAUNCH_CHECK();
 }

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 
@@ -73,9 +73,27 @@ def _pad_rows(x: torch.Tensor, rows: int) -> torch.Tensor:
     return out
 
 
+def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """Linear(LayerNorm(x)) with the affine part folded into the linear layer (modeling_videollama3_encoder.py:382-391):
+    LN(x) W^T + b = rstd (x - mean) (W diag(gamma))^T + (b + W beta). The rows of W' = W diag(gamma) are CENTRED (their
+    mean over the input dimension subtracted; zero-padded input columns excluded): sum_k x_k W''[n][k] then equals
+    sum_k (x_k - mean) W'[n][k] and the GEMM epilogue only evaluates rstd * acc + c (cogs_gemm_desc.ln_ab / col_c).
+    Returns (W'' rounded to W's dtype, s = fp32 row sums of the ROUNDED W'' -- the neglected residue, ~1e-2 |w| at
+    K = 1152 -- and c = fp32 b + W beta)."""
+    wd = w.double() * gamma.double()[None, :]
+    wd = wd - wd.mean(dim=1, keepdim=True)
+    wf = wd.to(w.dtype)
+    s = wf.double().sum(dim=1).float().contiguous()
+    c = (b.double() + w.double() @ beta.double()).float().contiguous()
+    return wf.contiguous(), s, c
+
+
 class PackedVit:
-    def __init__(self, state: Dict[str, torch.Tensor], cfg: VisionConfig, dtype=torch.bfloat16, device="cuda"):
+    def __init__(self, state: Dict[str, torch.Tensor], cfg: VisionConfig, dtype=torch.bfloat16, device="cuda",
+                 fold_ln: Optional[bool] = None):
+        """fold_ln (default: bf16 yes, fp32 no): fold layer_norm1 into the QKV projection and layer_norm2 into fc1"""
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.fold_ln = (dtype == torch.bfloat16 and cfg.hidden_size % 64 == 0) if fold_ln is None else bool(fold_ln)
         slab = k_slab(dtype)
         H, I, hd = cfg.hidden_size, cfg.intermediate_size, cfg.hidden_size // cfg.num_attention_heads
         self.inter_pad = (I + slab - 1) // slab * slab
@@ -102,16 +120,26 @@ class PackedVit:
             qb = _perm_heads(g(a + "q_proj.bias"), cfg.num_attention_heads, hd)
             kb = _perm_heads(g(a + "k_proj.bias"), cfg.num_attention_heads, hd)
             lay = self.layers[i]
-            lay.ln1_g = hold(g(p + "layer_norm1.weight")).data_ptr()
-            lay.ln1_b = hold(g(p + "layer_norm1.bias")).data_ptr()
-            lay.qkv_w = hold(torch.cat([qw, kw, g(a + "v_proj.weight")], 0)).data_ptr()
-            lay.qkv_b = hold(torch.cat([qb, kb, g(a + "v_proj.bias")], 0)).data_ptr()
+            ln1_g, ln1_b = hold(g(p + "layer_norm1.weight")), hold(g(p + "layer_norm1.bias"))
+            lay.ln1_g, lay.ln1_b = ln1_g.data_ptr(), ln1_b.data_ptr()
+            qkv_w = torch.cat([qw, kw, g(a + "v_proj.weight")], 0)
+            qkv_b = hold(torch.cat([qb, kb, g(a + "v_proj.bias")], 0))
+            if self.fold_ln:
+                qkv_w, s_, c_ = fold_layernorm(qkv_w, qkv_b, ln1_g, ln1_b)
+                lay.qkv_s, lay.qkv_c = hold(s_).data_ptr(), hold(c_).data_ptr()
+            lay.qkv_w = hold(qkv_w).data_ptr()
+            lay.qkv_b = qkv_b.data_ptr()
             lay.o_w = hold(g(a + "out_proj.weight")).data_ptr()
             lay.o_b = hold(g(a + "out_proj.bias")).data_ptr()
-            lay.ln2_g = hold(g(p + "layer_norm2.weight")).data_ptr()
-            lay.ln2_b = hold(g(p + "layer_norm2.bias")).data_ptr()
-            lay.fc1_w = hold(_pad_rows(g(p + "mlp.fc1.weight"), self.inter_pad)).data_ptr()
-            lay.fc1_b = hold(_pad_rows(g(p + "mlp.fc1.bias"), self.inter_pad)).data_ptr()
+            ln2_g, ln2_b = hold(g(p + "layer_norm2.weight")), hold(g(p + "layer_norm2.bias"))
+            lay.ln2_g, lay.ln2_b = ln2_g.data_ptr(), ln2_b.data_ptr()
+            fc1_w = _pad_rows(g(p + "mlp.fc1.weight"), self.inter_pad)
+            fc1_b = hold(_pad_rows(g(p + "mlp.fc1.bias"), self.inter_pad))
+            if self.fold_ln:
+                fc1_w, s_, c_ = fold_layernorm(fc1_w, fc1_b, ln2_g, ln2_b)
+                lay.fc1_s, lay.fc1_c = hold(s_).data_ptr(), hold(c_).data_ptr()
+            lay.fc1_w = hold(fc1_w).data_ptr()
+            lay.fc1_b = fc1_b.data_ptr()
             lay.fc2_w = hold(pad_cols(g(p + "mlp.fc2.weight"), slab)).data_ptr()
             lay.fc2_b = hold(g(p + "mlp.fc2.bias")).data_ptr()
         w = L.VitWeights()

@@ -106,8 +106,21 @@ typedef struct {
     const float* rope_lut;
     const int32_t* rope_rowpos;
     int rope_maxpos;
+    /* LayerNorm fused around the GEMM (nn.LayerNorm of modeling_videollama3_encoder.py:382-391; bf16/f32 alike):
+     * row_stats != NULL: the GEMM also writes, per output row and 64-column block, (sum, sum of squares) of its fp32
+     *   results: row_stats [M][N/64][2] fp32 (N % 64 == 0, no SWIGLU / fp32 output); cogs_ln_finalize turns them into
+     *   ln_ab [M][2] = (rstd, -rstd * mean).
+     * ln_ab != NULL: the GEMM computes LN(A) . W0^T + bias0 WITHOUT a normalised copy of A: W must hold
+     *   W0 * diag(gamma), col_s [N] = row sums of that W (fp32), col_c [N] = bias0 + W0 . beta (fp32), bias NULL; the
+     *   epilogue evaluates ln_ab[r][0] * acc + (ln_ab[r][1] * col_s[n] + col_c[n]) before rope / activation. */
+    float* row_stats;
+    const float* ln_ab;
+    const float* col_s;
+    const float* col_c;
 } cogs_gemm_desc;
 cogs_status cogs_gemm(cogs_stream stream, const cogs_gemm_desc* d);
+/* (rstd, -rstd * mean) per row from the row_stats partials of a GEMM whose N is the LayerNorm width H */
+cogs_status cogs_ln_finalize(cogs_stream stream, const float* row_stats, int rows, int H, float eps, float* ln_ab);
 
 /* Attention over token-major Q/K/V (row stride ld*, head h at column h*head_dim).
  * cu_seqlens (device int32 [nseg+1], nullable): block-diagonal segments as in
@@ -216,9 +229,15 @@ cogs_status cogs_sample(cogs_stream stream, const float* logits, int n, int top_
  * model.vision_encoder.{embeddings.patch_embedding, encoder.layers.N.*, post_layernorm}.
  * Packing done once at load (cogstream_amd/weights.py): patch_w [hidden, patch_pad] zero padded;
  * qkv_w [3*hidden, hidden] = q,k,v rows stacked, q/k rows of each head interleaved as rotary pairs;
- * fc1_w [inter_pad, hidden], fc1_b [inter_pad], fc2_w [hidden, inter_pad] zero padded. */
+ * fc1_w [inter_pad, hidden], fc1_b [inter_pad], fc2_w [hidden, inter_pad] zero padded.
+ * LayerNorm folding (bf16 production path; all four pointers non-NULL and hidden % 64 == 0): qkv_w / fc1_w then hold
+ * W * diag(ln_gamma) (rounded once to bf16), qkv_s / fc1_s [rows] fp32 = the row sums of those folded matrices and
+ * qkv_c / fc1_c [rows] fp32 = bias + W . ln_beta; the encoder then never materialises LN(x): the GEMMs that write the
+ * residual stream emit per-row statistics and the QKV / fc1 GEMMs apply them in their epilogue (cogs_gemm_desc.ln_ab).
+ * With the pointers NULL (fp32 parity mode) qkv_w / fc1_w are the plain weights and LayerNorm runs as its own kernel. */
 typedef struct {
     const void *ln1_g, *ln1_b, *qkv_w, *qkv_b, *o_w, *o_b, *ln2_g, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    const float *qkv_s, *qkv_c, *fc1_s, *fc1_c;
 } cogs_vit_layer;
 typedef struct {
     int dtype;

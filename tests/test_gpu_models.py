@@ -410,3 +410,26 @@ def test_real_dimension_llm_layer_vs_oracle(dev):
     for i in range(1100, 1103):
         r = eng.forward(emb[i:i + 1].to(dev, torch.bfloat16), cache)
         assert rel_err(r["logits"], oq.logits(st, hid[i])) < 3e-2
+
+
+def test_ragged_frame_shards_equal_whole_clip_bit_for_bit(dev):
+    """20 frames of the cfg3 grid (200 patches each) at the real ViT width, 3 layers: 4000 rows whole, 2 x 2000 rows
+    sharded -- 2000 is not a multiple of the 256-row GEMM tile, so the last frames of a shard run through the
+    ragged-block epilogues (general path, per-row rotary table) while the same rows sit in interior tiles (pair
+    epilogue, LDS rotary LUT, LayerNorm statistics / folding) in the whole-clip encode. Frame sharding over GPUs
+    relies on the two agreeing bit for bit (every epilogue spells the rotary rotation and the row statistics the same
+    way: csrc/gemm_epilogue.h rope_rot / EPI_ROWSTAT)."""
+    from cogstream_amd.vision import VisionEncoder
+    from cogstream_amd.weights import VisionConfig, random_vit_state
+    cfg = VisionConfig(num_hidden_layers=3)
+    enc = VisionEncoder(random_vit_state(cfg, 0, dev, torch.bfloat16), cfg, device=dev)
+    assert enc.packed.fold_ln                                            # the production configuration
+    T, gh, gw = 20, 10, 20
+    g = torch.Generator(device=dev).manual_seed(3)
+    pix = (torch.rand(T * gh * gw, 588, generator=g, device=dev) * 2 - 1).bfloat16()
+    merge = torch.tensor([2])
+    whole = enc(pix, torch.tensor([[T, gh, gw]]), merge).clone()
+    for cut in (10, 7):
+        a = enc(pix[:cut * 200], torch.tensor([[cut, gh, gw]]), merge).clone()
+        b = enc(pix[cut * 200:], torch.tensor([[T - cut, gh, gw]]), merge).clone()
+        assert torch.equal(whole, torch.cat([a, b])), cut

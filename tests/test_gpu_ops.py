@@ -488,3 +488,61 @@ def test_pair_epilogue_and_relaxed_vmcnt_equal_the_generic_build_bit_for_bit(dev
             b = ops.gemm(**kw, lib=alt)
             torch.cuda.synchronize()
             assert torch.equal(a, b), (name, rep, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("M", [300, 1300, 4096])
+def test_gemm_row_stats_and_ln_fold(dev, M):
+    """LayerNorm fused around the GEMMs: (1) a residual-stream GEMM (N = hidden) also writes per-row partial sums,
+    cogs_ln_finalize turns them into (rstd, -rstd * mean); (2) the consuming GEMM reads x itself with W * diag(gamma)
+    (rows centred) and applies rstd_r * acc + c_n -- together LN(x) W^T + bias of nn.LayerNorm + nn.Linear
+    (model/modeling_videollama3_encoder.py:382-391). M = 300 / 1300 / 4096 reach the 128x128, 256x128 + ragged ping-pong
+    and the full ping-pong kernels."""
+    ops = _ops()
+    torch.manual_seed(M)
+    H, N2, eps = 1152, 1472, 1e-6
+    a0 = torch.randn(M, 256).bfloat16()
+    w0 = (torch.randn(H, 256) / 16).bfloat16()
+    b0 = torch.randn(H).bfloat16()
+    res = (torch.randn(M, H) * 2 + 0.7).bfloat16()                       # rows with a clearly non-zero mean
+    res[::7] += 16.0                                                     # and some with |mean / std| ~ 8
+    y32 = a0.float() @ w0.float().t() + b0.float() + res.float()
+    part = torch.zeros(M, H // 64, 2, device=dev)
+    x = ops.gemm(a0.to(dev), w0.to(dev), b0.to(dev), residual=res.to(dev), row_stats=part)
+    assert rel_err(x.float(), y32) < 1.2e-2
+    want = torch.stack([y32.view(M, H // 64, 64).sum(-1), (y32 ** 2).view(M, H // 64, 64).sum(-1)], -1)
+    assert rel_err(part, want) < 1e-4
+    ab = ops.ln_finalize(part, H, eps)
+    mean, var = y32.mean(1), y32.var(1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    assert rel_err(ab[:, 0], rstd) < 1e-4 and rel_err(ab[:, 1], -rstd * mean) < 1e-4
+    # consumer: fc1-like (GELU) and plain
+    gamma, beta = (1 + 0.3 * torch.randn(H)).bfloat16(), (0.2 * torch.randn(H)).bfloat16()
+    w1 = (torch.randn(N2, H) / 30).bfloat16()
+    b1 = torch.randn(N2).bfloat16()
+    from cogstream_amd.weights import fold_layernorm
+    wf, col_s, col_c = fold_layernorm(w1, b1, gamma, beta)               # W * gamma with centred rows, s ~ 0, c = b + W beta
+    assert float(col_s.abs().max()) < 0.05 * float(wf.float().abs().sum(1).mean())
+    xr = x.float().cpu()
+    ln = F.layer_norm(xr, (H,), gamma.float(), beta.float(), eps)
+    for act, fn in ((L_ACT_NONE(), lambda t: t), (L_ACT_GELU(), lambda t: F.gelu(t, approximate="tanh"))):
+        ref = fn(ln @ w1.float().t() + b1.float())
+        out = ops.gemm(x, wf.to(dev), None, act=act, ln_ab=ab, col_s=col_s.to(dev), col_c=col_c.to(dev))
+        unfused = ops.gemm(ln.bfloat16().to(dev), w1.to(dev), b1.to(dev), act=act)
+        # rows with an ordinary mean: as accurate as the unfused bf16 path. Rows with |mean / std| ~ 8: the rounding of
+        # the folded weights is seen through x itself instead of through the normalised x, i.e. amplified by
+        # sqrt(1 + (mean/std)^2) (DESIGN.md section 4) -- still within bf16-level error of the row's output scale
+        big = torch.zeros(M, dtype=torch.bool)
+        big[::7] = True
+        for rows, amp in ((~big, 1.0), (big, 9.0)):
+            e_f, e_u = rel_err(out.float().cpu()[rows], ref[rows]), rel_err(unfused.float().cpu()[rows], ref[rows])
+            assert e_f < amp * (2.0 * e_u + 2e-3), (act, amp, e_f, e_u)
+
+
+def L_ACT_NONE():
+    from cogstream_amd import _lib as L
+    return L.ACT_NONE
+
+
+def L_ACT_GELU():
+    from cogstream_amd import _lib as L
+    return L.ACT_GELU_TANH
