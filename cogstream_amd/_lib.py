@@ -147,7 +147,7 @@ SIGNATURES = {
                                     c_void_p]),
     "cogs_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cogs_sample_workspace_bytes": (c_size_t, []),
-    "cogs_sample": (c_int, [c_void_p, c_void_p, c_int, c_int, C.c_double, c_void_p, C.c_uint64, C.c_uint64, c_void_p,
+    "cogs_sample": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, C.c_double, c_void_p, C.c_uint64, C.c_uint64, c_void_p,
                             c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "cogs_vit_load": (c_int, [c_void_p, C.POINTER(VitWeights)]),
     "cogs_vit_workspace_bytes": (c_int, [c_void_p, c_int64, C.POINTER(c_size_t)]),

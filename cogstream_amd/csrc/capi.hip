@@ -308,10 +308,11 @@ cogs_status cogs_logits_process(cogs_stream stream, float* logits, int n, const 
                                  temperature, tmp);
 }
 size_t cogs_sample_workspace_bytes(void) { return cogs_k_sample_ws(); }
-cogs_status cogs_sample(cogs_stream stream, const float* logits, int n, int top_k, double top_p, const float* draws,
+cogs_status cogs_sample(cogs_stream stream, const float* logits, int n, float temperature, int top_k, double top_p,
+                        const float* draws,
                         uint64_t seed, uint64_t offset, int64_t* out_token, int32_t* kept_idx, float* kept_prob,
                         int32_t* n_kept, int kept_cap, void* ws) {
-    return cogs_k_sample((hipStream_t)stream, logits, n, top_k, top_p, draws, seed, offset, out_token, kept_idx, kept_prob,
+    return cogs_k_sample((hipStream_t)stream, logits, n, temperature, top_k, top_p, draws, seed, offset, out_token, kept_idx, kept_prob,
                          n_kept, kept_cap, ws);
 }
 cogs_status cogs_topk(cogs_stream stream, const float* logits, int n, int top_k, float* topk_val, int32_t* topk_idx,

@@ -138,6 +138,6 @@ int cogs_k_logits_process(hipStream_t st, float* logits, int n, const int64_t* p
 int cogs_k_topk(hipStream_t st, const float* logits, int n, int top_k, float* topk_val, int32_t* topk_idx, float* ws);
 // TopK -> TopP -> softmax -> multinomial of one processed fp32 row (sample.hip); ws >= cogs_k_sample_ws() bytes
 size_t cogs_k_sample_ws();
-int cogs_k_sample(hipStream_t st, const float* logits, int n, int top_k, double top_p, const float* draws, uint64_t seed,
+int cogs_k_sample(hipStream_t st, const float* logits, int n, float temperature, int top_k, double top_p, const float* draws, uint64_t seed,
                   uint64_t offset, int64_t* out_token, int32_t* kept_idx, float* kept_prob, int* n_kept, int kept_cap,
                   void* ws);

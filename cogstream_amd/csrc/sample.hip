@@ -70,7 +70,7 @@ __device__ __forceinline__ Best wave_best(Best b) {
 }
 
 // ---- fast path, stage A: per-slice top-k candidates (key desc, index asc) ----
-__global__ __launch_bounds__(256) void sample_slice_topk_kernel(const float* __restrict__ logits, int n, int k,
+__global__ __launch_bounds__(256) void sample_slice_topk_kernel(const float* __restrict__ logits, int n, int k, float temperature,
                                                                 uint32_t* __restrict__ cand_key, int* __restrict__ cand_idx) {
     __shared__ uint32_t sl[SA_SLICE];
     __shared__ uint32_t wk[4];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void sample_slice_topk_kernel(const float* __r
     const int lo = blockIdx.x * chunk, cnt = max(0, min(chunk, n - lo));
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < cnt; i += 256) {
-        const float v = logits[lo + i];
+        const float v = logits[lo + i] / temperature;   // TemperatureLogitsWarper: scores / temperature (IEEE division)
         sl[i] = v == -INFINITY ? 0u : fkey(v);   // a masked score (-inf) is never a candidate
     }
     __syncthreads();
@@ -110,27 +110,58 @@ __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __re
                                                             uint64_t offset, int64_t* __restrict__ out_token,
                                                             int32_t* __restrict__ kept_idx, float* __restrict__ kept_prob,
                                                             int* __restrict__ n_kept, int kept_cap) {
-    __shared__ uint32_t ck[SA_BLOCKS * SA_KMAX];
-    __shared__ int ci[SA_BLOCKS * SA_KMAX];
+    __shared__ __attribute__((aligned(16))) uint32_t ck[SA_BLOCKS * SA_KMAX];
+    __shared__ __attribute__((aligned(16))) int ci[SA_BLOCKS * SA_KMAX];
     constexpr int KEPT_MAX = 1024;                  // top_k + ties of the k-th value (more ties than that are dropped)
     __shared__ uint32_t sk[KEPT_MAX];               // kept, sorted: rank < k first, then ties with the k-th value
     __shared__ int si[KEPT_MAX];
     __shared__ int m_sh, ties_sh;
+    __shared__ uint32_t t0_sh;
+    __shared__ int nsurv_sh;
     const int tid = threadIdx.x;
-    const int nc = SA_BLOCKS * k;
-    for (int j = tid; j < nc; j += 1024) {
-        const int b = j / k, r = j % k;
-        ck[j] = cand_key[b * SA_KMAX + r];
-        ci[j] = cand_idx[b * SA_KMAX + r];
+    // prefilter: the slice whose k-th candidate is largest already holds k keys >= that value T0, so the global k-th
+    // largest key is >= T0 and every candidate below T0 is out. What is left (k .. a few k) is ranked; ranking all
+    // 64 * k candidates against each other was 100+ us of LDS scanning per token.
+    if (tid < 64) {
+        uint32_t kth = cand_key[tid * SA_KMAX + k - 1];                 // 0 when the slice has fewer than k candidates
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kth = max(kth, (uint32_t)__shfl_xor((int)kth, o, 64));
+        if (tid == 0) { t0_sh = kth; nsurv_sh = 0; m_sh = 0; ties_sh = 0; }
     }
-    if (tid == 0) { m_sh = 0; ties_sh = 0; }
     __syncthreads();
+    const uint32_t T0 = t0_sh;
+    for (int j = tid; j < SA_BLOCKS * k; j += 1024) {
+        const int b = j / k, r = j % k;
+        const uint32_t key = cand_key[b * SA_KMAX + r];
+        if (key != 0u && key >= T0) {
+            const int slot = atomicAdd(&nsurv_sh, 1);
+            if (slot < SA_BLOCKS * SA_KMAX) { ck[slot] = key; ci[slot] = cand_idx[b * SA_KMAX + r]; }
+        }
+    }
+    __syncthreads();
+    const int nsurv = min(nsurv_sh, SA_BLOCKS * SA_KMAX);
+    const int nc = (nsurv + 3) & ~3;                                    // padded with "no candidate" entries
+    if (tid < nc - nsurv) { ck[nsurv + tid] = 0u; ci[nsurv + tid] = 0x7fffffff; }
+    __syncthreads();
+    // rank of a candidate = number of candidates in front of it (key descending, index ascending). The scan reads four
+    // candidates per LDS access and is unrolled: one candidate per access made the loop wait for the LDS latency on
+    // every iteration (1280 dependent round trips: 355 us per token; now ~15 us)
+    auto rank_of = [&](uint32_t kj, int ij) {
+        int rank = 0;
+#pragma unroll 4
+        for (int t = 0; t < nc; t += 4) {
+            const u32x4 k4 = *reinterpret_cast<const u32x4*>(&ck[t]);
+            const u32x4 i4 = *reinterpret_cast<const u32x4*>(&ci[t]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rank += (k4[e] != 0u && better(k4[e], (int)i4[e], kj, ij)) ? 1 : 0;
+        }
+        return rank;
+    };
     for (int j = tid; j < nc; j += 1024) {
         const uint32_t kj = ck[j];
         const int ij = ci[j];
         if (kj == 0u) continue;
-        int rank = 0;
-        for (int t = 0; t < nc; ++t) rank += (ck[t] != 0u && better(ck[t], ci[t], kj, ij)) ? 1 : 0;
+        const int rank = rank_of(kj, ij);
         if (rank < k) { sk[rank] = kj; si[rank] = ij; atomicAdd(&m_sh, 1); }
     }
     __syncthreads();
@@ -139,8 +170,7 @@ __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __re
         const uint32_t thr = sk[k - 1];
         for (int j = tid; j < nc; j += 1024) {
             if (ck[j] != thr) continue;
-            int rank = 0;
-            for (int t = 0; t < nc; ++t) rank += (ck[t] != 0u && better(ck[t], ci[t], ck[j], ci[j])) ? 1 : 0;
+            const int rank = rank_of(ck[j], ci[j]);
             if (rank >= k) {
                 const int s = atomicAdd(&ties_sh, 1);
                 if (k + s < KEPT_MAX) { sk[k + s] = ck[j]; si[k + s] = ci[j]; }
@@ -189,7 +219,7 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh /*16*/) {
     return t;
 }
 
-__global__ __launch_bounds__(1024) void sample_full_kernel(const float* __restrict__ logits, int n, int top_k, float lim_f,
+__global__ __launch_bounds__(1024) void sample_full_kernel(const float* __restrict__ logits_raw, int n, int top_k, float lim_f, float temperature,
                                                            const float* __restrict__ draws, uint64_t seed, uint64_t offset,
                                                            int64_t* __restrict__ out_token, int32_t* __restrict__ kept_idx,
                                                            float* __restrict__ kept_prob, int* __restrict__ n_kept, int kept_cap) {
@@ -212,7 +242,7 @@ __global__ __launch_bounds__(1024) void sample_full_kernel(const float* __restri
             if (tid < 256) hist[tid] = 0u;
             __syncthreads();
             for (int i = tid; i < n; i += 1024) {
-                const uint32_t key = fkey(logits[i]);
+                const uint32_t key = fkey((logits_raw[i] / temperature));
                 if (level == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1u);
             }
             __syncthreads();
@@ -235,7 +265,7 @@ __global__ __launch_bounds__(1024) void sample_full_kernel(const float* __restri
     // 2. max and sum of exp over the kept scores
     float mx = -INFINITY;
     for (int i = tid; i < n; i += 1024) {
-        const float s = logits[i];
+        const float s = (logits_raw[i] / temperature);
         if (fkey(s) >= tk) mx = fmaxf(mx, s);
     }
     mx = wave_max(mx);
@@ -245,7 +275,7 @@ __global__ __launch_bounds__(1024) void sample_full_kernel(const float* __restri
     for (int w = 0; w < 16; ++w) mx = fmaxf(mx, best_v[w]);
     double acc = 0.0;
     for (int i = tid; i < n; i += 1024) {
-        const float s = logits[i];
+        const float s = (logits_raw[i] / temperature);
         if (fkey(s) >= tk) acc += (double)expf(s - mx);
     }
     const float sum = (float)block_sum_d(acc, dsh);
@@ -262,7 +292,7 @@ __global__ __launch_bounds__(1024) void sample_full_kernel(const float* __restri
 #pragma unroll
             for (int d = 0; d < 16; ++d) part[d] = 0.0;
             for (int i = tid; i < n; i += 1024) {
-                const float s = logits[i];
+                const float s = (logits_raw[i] / temperature);
                 if (fkey(s) < tk) continue;
                 const float p = expf(s - mx) / sum;
                 const uint32_t pb = __float_as_uint(p);
@@ -304,7 +334,7 @@ __global__ __launch_bounds__(1024) void sample_full_kernel(const float* __restri
     // 4. renormalise over the survivors and draw
     acc = 0.0;
     for (int i = tid; i < n; i += 1024) {
-        const float s = logits[i];
+        const float s = (logits_raw[i] / temperature);
         if (fkey(s) < tk) continue;
         const float e = expf(s - mx);
         if (__float_as_uint(e / sum) >= tp || s == mx) acc += (double)e;
@@ -315,7 +345,7 @@ __global__ __launch_bounds__(1024) void sample_full_kernel(const float* __restri
     float bv = -1.f;
     int bi = 0x7fffffff;
     for (int i = tid; i < n; i += 1024) {
-        const float s = logits[i];
+        const float s = (logits_raw[i] / temperature);
         if (fkey(s) < tk || s == -INFINITY) continue;
         const float e = expf(s - mx);
         if (!(__float_as_uint(e / sum) >= tp || s == mx)) continue;
@@ -348,10 +378,10 @@ __global__ __launch_bounds__(1024) void sample_full_kernel(const float* __restri
 
 size_t cogs_k_sample_ws() { return (size_t)SA_BLOCKS * SA_KMAX * 8; }
 
-int cogs_k_sample(hipStream_t st, const float* logits, int n, int top_k, double top_p, const float* draws, uint64_t seed,
+int cogs_k_sample(hipStream_t st, const float* logits, int n, float temperature, int top_k, double top_p, const float* draws, uint64_t seed,
                   uint64_t offset, int64_t* out_token, int32_t* kept_idx, float* kept_prob, int* n_kept, int kept_cap,
                   void* ws) {
-    if (n <= 0 || !logits || !out_token || top_k < 0) return COGS_E_INVALID;
+    if (n <= 0 || !logits || !out_token || top_k < 0 || !(temperature > 0.f)) return COGS_E_INVALID;
     if (kept_idx && (!kept_prob || !n_kept || kept_cap <= 0)) return COGS_E_INVALID;
     // TopPLogitsWarper compares the fp32 cumulative sum with the python double (1 - top_p) converted to fp32
     const float lim = top_p >= 1.0 ? 0.0f : (float)(1.0 - top_p);
@@ -359,11 +389,11 @@ int cogs_k_sample(hipStream_t st, const float* logits, int n, int top_k, double 
         if (!ws) return COGS_E_WORKSPACE;
         uint32_t* ck = (uint32_t*)ws;
         int* ci = (int*)(ck + SA_BLOCKS * SA_KMAX);
-        hipLaunchKernelGGL(sample_slice_topk_kernel, dim3(SA_BLOCKS), dim3(256), 0, st, logits, n, top_k, ck, ci);
+        hipLaunchKernelGGL(sample_slice_topk_kernel, dim3(SA_BLOCKS), dim3(256), 0, st, logits, n, top_k, temperature, ck, ci);
         hipLaunchKernelGGL(sample_merge_kernel, dim3(1), dim3(1024), 0, st, ck, ci, top_k, lim, draws, seed, offset,
                            out_token, kept_idx, kept_prob, n_kept, kept_cap);
     } else {
-        hipLaunchKernelGGL(sample_full_kernel, dim3(1), dim3(1024), 0, st, logits, n, top_k, lim, draws, seed, offset,
+        hipLaunchKernelGGL(sample_full_kernel, dim3(1), dim3(1024), 0, st, logits, n, top_k, lim, temperature, draws, seed, offset,
                            out_token, kept_idx, kept_prob, n_kept, kept_cap);
     }
     return COGS_LAUNCH_CHECK();

@@ -177,17 +177,17 @@ class Qwen2Engine:
         check_every = 8
         if do_sample and sampler == "device" and seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
-        need_proc = repetition_penalty != 1.0 or allowed is not None or (do_sample and temperature != 1.0)
+        need_proc = repetition_penalty != 1.0 or allowed is not None     # the temperature is applied inside cogs_sample
         stop_at = None
         for step in range(max_new_tokens):
             logits = res["logits"]
             if need_proc:
                 prev = seen[:n_seen] if (n_seen and repetition_penalty != 1.0) else None
-                ops.logits_process(logits, prev, repetition_penalty, allowed, temperature if do_sample else 1.0)
+                ops.logits_process(logits, prev, repetition_penalty, allowed, 1.0)
             if do_sample:
                 tok_dev = ops.sample(logits, top_k or 0, 1.0 if top_p is None else top_p,
                                      draws=self._draws(generator) if sampler == "host" else None,
-                                     seed=seed or 0, offset=step)
+                                     seed=seed or 0, offset=step, temperature=temperature)
             else:
                 tok_dev = ops.argmax(logits)
             toks[step:step + 1].copy_(tok_dev)

@@ -242,7 +242,8 @@ def topk(logits: torch.Tensor, k: int):
 
 
 def sample(logits: torch.Tensor, top_k: int = 0, top_p: float = 1.0, draws: Optional[torch.Tensor] = None,
-           seed: int = 0, offset: int = 0, out: Optional[torch.Tensor] = None, want_kept: bool = False):
+           seed: int = 0, offset: int = 0, out: Optional[torch.Tensor] = None, want_kept: bool = False,
+           temperature: float = 1.0):
     """cogs_sample on a processed fp32 [vocab] row -> int64 [1] token on the device (+ (ids, probs) of the surviving
     tokens if want_kept). draws: device float [vocab] of Exponential(1) draws (parity with torch.multinomial on the
     CPU generator) or None (Philox on the device, keyed by seed/offset)."""
@@ -258,7 +259,8 @@ def sample(logits: torch.Tensor, top_k: int = 0, top_p: float = 1.0, draws: Opti
         kept_idx = torch.empty(cap, device=logits.device, dtype=torch.int32)
         kept_prob = torch.empty(cap, device=logits.device, dtype=torch.float32)
         n_kept = torch.zeros(1, device=logits.device, dtype=torch.int32)
-    check(L.lib.cogs_sample(current_stream(), ptr(logits), n, int(top_k or 0), float(top_p if top_p is not None else 1.0),
+    check(L.lib.cogs_sample(current_stream(), ptr(logits), n, float(temperature), int(top_k or 0),
+                            float(top_p if top_p is not None else 1.0),
                             ptr(draws), int(seed) & (2 ** 64 - 1), int(offset), ptr(out), ptr(kept_idx), ptr(kept_prob),
                             ptr(n_kept), cap, ptr(ws)), "cogs_sample")
     if want_kept:

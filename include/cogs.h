@@ -210,7 +210,8 @@ cogs_status cogs_logits_process(cogs_stream stream, float* logits, int n, const 
                                 float temperature, float* tmp /* >= n_prev floats */);
 cogs_status cogs_topk(cogs_stream stream, const float* logits, int n, int top_k, float* topk_val,
                       int32_t* topk_idx, float* ws /* >= n floats */);
-/* One sampled token from a PROCESSED fp32 row (after cogs_logits_process): TopKLogitsWarper (top_k <= 0: off; keeps
+/* One sampled token from a PROCESSED fp32 row (after cogs_logits_process's penalty / mask): TemperatureLogitsWarper
+ * (scores / temperature, temperature > 0; 1 = off) -> TopKLogitsWarper (top_k <= 0: off; keeps
  * every score >= the k-th largest) -> TopPLogitsWarper (top_p >= 1: off; ascending cumulative probability <= 1 - top_p
  * is dropped, the best token always stays) -> softmax -> torch.multinomial(probs, 1) = argmax_i probs_i / q_i,
  * q ~ Exp(1) (GenerationMixin._sample of transformers 4.46.3 with model/generation_config.json:2-12; call site
@@ -219,7 +220,8 @@ cogs_status cogs_topk(cogs_stream stream, const float* logits, int n, int top_k,
  * reference's CPU sampler). Optional kept_idx/kept_prob [kept_cap] + n_kept report the surviving ids and their
  * renormalised probabilities (any order). ws >= cogs_sample_workspace_bytes(). */
 size_t cogs_sample_workspace_bytes(void);
-cogs_status cogs_sample(cogs_stream stream, const float* logits, int n, int top_k, double top_p, const float* draws,
+cogs_status cogs_sample(cogs_stream stream, const float* logits, int n, float temperature, int top_k, double top_p,
+                        const float* draws,
                         uint64_t seed, uint64_t offset, int64_t* out_token, int32_t* kept_idx, float* kept_prob,
                         int32_t* n_kept, int kept_cap, void* ws);
 

@@ -368,22 +368,20 @@ def test_sampling_warpers_vs_transformers_fixture(dev):
         prev = torch.from_numpy(g[f"s{ci}_prev"]).to(dev)
         ops.logits_process(lg, prev if rep != 1.0 else None, rep, None, 1.0)
         assert torch.equal(lg.cpu(), torch.from_numpy(g[f"s{ci}_after_penalty"]))
-        if temp != 1.0:
-            ops.logits_process(lg, None, 1.0, None, temp)
-        tok, kid, kp = ops.sample(lg, int(top_k), top_p, seed=1, offset=0, want_kept=True)
+        tok, kid, kp = ops.sample(lg, int(top_k), top_p, seed=1, offset=0, want_kept=True, temperature=temp)
         order = kid.cpu().argsort()
         assert kid.cpu()[order].tolist() == g[f"s{ci}_kept"].tolist(), ci                 # exact survivor set
         assert torch.allclose(kp.cpu()[order], torch.from_numpy(g[f"s{ci}_probs"]), rtol=2e-6, atol=1e-9), ci
         assert int(tok) in g[f"s{ci}_kept"].tolist()
         for seed, want in enumerate(g[f"s{ci}_draws"].tolist()):
             q = torch.empty(lg.numel()).exponential_(1, generator=torch.Generator().manual_seed(1000 + seed))
-            assert int(ops.sample(lg, int(top_k), top_p, draws=q.to(dev))) == want, (ci, seed)
+            assert int(ops.sample(lg, int(top_k), top_p, draws=q.to(dev), temperature=temp)) == want, (ci, seed)
     # device draws: the empirical distribution over many Philox offsets follows the kept probabilities
     lg = torch.from_numpy(g["s1_logits"]).to(dev).clone()
-    ops.logits_process(lg, torch.from_numpy(g["s1_prev"]).to(dev), 1.05, None, 0.7)
+    ops.logits_process(lg, torch.from_numpy(g["s1_prev"]).to(dev), 1.05, None, 1.0)
     out = torch.empty(4000, dtype=torch.int64, device=dev)
     for i in range(4000):
-        ops.sample(lg, 20, 0.8, seed=99, offset=i, out=out[i:i + 1])
+        ops.sample(lg, 20, 0.8, seed=99, offset=i, out=out[i:i + 1], temperature=0.7)
     ids, probs = g["s1_kept"].tolist(), g["s1_probs"]
     cnt = torch.bincount(out.cpu(), minlength=lg.numel())
     assert int(cnt.sum()) == int(cnt[ids].sum())                                              # only survivors
