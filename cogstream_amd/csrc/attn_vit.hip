@@ -350,6 +350,305 @@ __global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined variant with LDS-DMA staging: the same products, padding trick and deferred maximum, but
+//   (1) a wave's instruction stream always holds independent matrix AND vector work:
+//         iteration t:   P(t) = exp2(S(t))   beside   S(t+1) = K(t+1).Q^T
+//                        O += V(t)^T.P(t)    beside   max over S(t+1)
+//       An MFMA occupies the matrix pipe for 32 cycles after a 4-cycle issue; the wave issues independent VALU / LDS
+//       work into that shadow. In the unpipelined kernel above a wave alternates between pure-MFMA and pure-VALU
+//       stretches and the two waves that share a SIMD fall into step -- measured with staging removed: 1 360 cycles
+//       per wave and tile = the plain SUM of its 704 MFMA cycles and its VALU stream, no overlap at all;
+//   (2) K/V tiles go global -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write, no load -> write
+//       dependency inside the loop) into a ring of FOUR tile slots, three tiles ahead. A tile is the plain image of
+//       its 64 rows x 144 bytes: the 144-byte row stride is conflict-free for the K fragment reads (36 dwords: the 16
+//       rows of a ds_read_b128 lane group start at 16 different multiples of 4 banks) and costs the transposing V
+//       reads a 2-way conflict on half their lanes. The pad column has no room in that image: the lanes that would
+//       read it (K: k-half 1 of the last k-step; V: the pieces d = 72..95 of the last d-block) are pointed at a
+//       constant chunk [1, 0 x7] / zeros behind the tile instead.
+// S(t) and S(t+1) live in two register sets that swap roles between the halves of a manually unrolled loop pair; the
+// ragged end runs through one generic, copying body. Rows past the segment end are read from its last row (finite
+// data, their scores are masked), never from outside.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
+    constexpr int NT = 256, QB = 128, NS = 4;
+    static_assert(HD % 8 == 0 && HD % 16 == 8 && HD < 96, "pad column HD must open a fresh 16-byte chunk inside the last k-step");
+    constexpr int KS = (HD + 8) / 16, DB = (HD + 8 + 31) / 32, CH = HD / 8;
+    constexpr int RS = HD * 2;                        // LDS row stride = the row itself (144 B)
+    constexpr int TILE = 64 * RS;                     // 9216
+    constexpr int PIECES = TILE / 1024;               // 9 DMA pieces of 1 KiB per matrix and tile
+    static_assert(TILE % 1024 == 0, "a tile is a whole number of 1 KiB pieces");
+    constexpr int C_ONE = 2 * TILE, C_ZERO = 2 * TILE + 16, STAGE = 2 * TILE + 64;     // [K | V | one-chunk | zero-chunk | -]
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r32 = lane & 31;
+    int seg, head, qb;
+    {
+        const int nhf = p.nseg * p.heads, id = blockIdx.x;      // XCD-aware order, see attn_vit_kernel
+        if (nhf % 8 == 0) {
+            const int slot = id & 7, rest = id >> 3;
+            qb = rest % p.nqb;
+            const int hf = (rest / p.nqb) * 8 + slot;
+            seg = hf / p.heads; head = hf % p.heads;
+        } else {
+            qb = id % p.nqb; head = (id / p.nqb) % p.heads; seg = id / (p.nqb * p.heads);
+        }
+    }
+    const int qs = p.cu[seg], qe = p.cu[seg + 1];
+    const int q0 = qs + qb * QB;
+    if (q0 >= qe) return;
+    const int nt = (qe - qs + 63) >> 6;
+    const int full_tiles = (qe - qs) >> 6;
+
+    if (tid < NS) {                                              // constant chunks, written once
+        *reinterpret_cast<u32x4*>(smem + tid * STAGE + C_ONE) = u32x4{0x00003f80u, 0, 0, 0};
+        *reinterpret_cast<u32x4*>(smem + tid * STAGE + C_ZERO) = u32x4{0, 0, 0, 0};
+    }
+
+    const int qrow = q0 + wid * 32 + r32;
+    const bool qok = qrow < qe;
+    const bool wave_active = q0 + wid * 32 < qe;
+    u32x4 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 16 * s + 8 * h;
+        qf[s] = u32x4{0, 0, 0, 0};
+        if (qok && k < HD) qf[s] = *reinterpret_cast<const u32x4*>(p.Q + (long)qrow * p.ldq + head * HD + k);
+    }
+
+    // DMA pieces: piece j (0..8) of a matrix covers chunks 64j..64j+63 of the tile image (chunk c = row c / 9, 16-byte
+    // column c % 9). Wave w issues pieces w and w + 4 of K and of V; piece 8 of K goes to wave 0, of V to wave 1.
+    const int n_own = wid < 2 ? 5 : 4;                           // this wave's DMA instructions per tile
+    int pc_row[3], pc_off[3];                                    // per-lane row and byte offset of the wave's pieces
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = (i < 2 ? wid + 4 * i : 8) * 64 + lane;
+        pc_row[i] = c / CH;
+        pc_off[i] = (pc_row[i] * (int)p.ldk + head * HD + (c % CH) * 8) * 2;   // bytes; ldk == ldv (checked by the launcher)
+    }
+    // The DMA is issued from inline assembly: hipcc's wait insertion treats a `global_load_lds` it can see as a pending
+    // LDS store and puts `s_waitcnt vmcnt(0)` in front of the first ds_read_b64_tr_b16 of every tile (the transposing
+    // read carries no memory operand to disambiguate), which would drain the three-tile prefetch every iteration. Hidden
+    // vector-memory operations only make the compiler's own vmcnt waits (Q loads, O stores) more conservative.
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma16 = [&](const bf16_t* base, int off_bytes, unsigned lds) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(lds), "v"(off_bytes), "s"(base) : "memory");
+    };
+    auto issue_tile = [&](int t) {
+        const int kbase = qs + t * 64;
+        const int valid = qe - kbase;                            // >= 1
+        const bf16_t* kb = p.K + (long)kbase * p.ldk;
+        const bf16_t* vb = p.V + (long)kbase * p.ldv;
+        const unsigned st = smem_lds + (t & (NS - 1)) * STAGE;
+        int off[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) off[i] = pc_off[i];
+        if (valid < 64) {                                        // ragged last tile: rows past the end repeat the last row
+#pragma unroll
+            for (int i = 0; i < 3; ++i) off[i] = pc_off[i] - (pc_row[i] - min(pc_row[i], valid - 1)) * (int)p.ldk * 2;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dma16(kb, off[i], st + (wid + 4 * i) * 1024);
+            dma16(vb, off[i], st + TILE + (wid + 4 * i) * 1024);
+        }
+        if (wid == 0) dma16(kb, off[2], st + 8 * 1024);
+        if (wid == 1) dma16(vb, off[2], st + TILE + 8 * 1024);
+    };
+    // this wave's pieces of every tile but the `newer` most recently issued ones have landed
+    auto wait_tiles = [&](int newer) {
+        if (newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (newer == 1) { if (n_own == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else { if (n_own == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    };
+
+    // per-lane LDS read offsets inside a stage. K: lane (key r32, k-half h) reads 16 bytes at column 32 ks + 16 h; in
+    // the last k-step half 1 is the pad chunk -> constant [1, 0 x7]
+    const int k_rd = r32 * RS + h * 16;
+    int k_last[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) k_last[kb] = h ? C_ONE : k_rd + kb * 32 * RS + (KS - 1) * 32;
+    // V: lane supplies the 8-byte piece (key 4h + ((lane & 15) >> 2) [+8], d = 32 b + 16 ((lane >> 4) & 1) + 4 (lane & 3) .. +3)
+    const int v_d = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int v_rd = TILE + (4 * h + ((lane & 15) >> 2)) * RS + v_d * 2;
+    // last d-block: d = 32 (DB - 1) + v_d; real data below HD, [1, 0, 0, 0] at HD, zeros above
+    constexpr int DL = 32 * (DB - 1);
+    const bool v_last_real = DL + v_d < HD;
+    const int v_last_const = DL + v_d == HD ? C_ONE : C_ZERO;
+
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[b][r] = 0.f;
+    float sh = 0.f;
+
+    // S^T - m of one tile into s[2]; MASKED: keys >= valid get -inf
+    auto qk = [&](const char* st, f32x16 (&s)[2], const int valid, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 kf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS - 1; ++ks) kf[ks] = *reinterpret_cast<const u32x4*>(st + k_rd + kb * 32 * RS + ks * 32);
+            kf[KS - 1] = *reinterpret_cast<const u32x4*>(st + k_last[kb]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                f32x16 c0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), __builtin_bit_cast(bf16x8, qf[ks]),
+                                                                ks == 0 ? c0 : s[kb], 0, 0, 0);
+            }
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= valid) s[kb][r] = -INFINITY;
+                }
+        }
+    };
+    auto row_max = [&](const f32x16 (&s)[2]) -> float {
+        float d = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) d = fmaxf(d, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d = fmaxf(d, s[1][r]);
+        const unsigned db = __builtin_bit_cast(unsigned, d);
+        const auto sw = __builtin_amdgcn_permlane32_swap(db, db, false, false);
+        return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    };
+    auto set_shift = [&](float m_new) {
+        sh = m_new;
+        const unsigned bits = __float_as_uint(-sh) >> 16;          // exact: sh is a bf16 value
+        if (h) qf[KS - 1][0] = (qf[KS - 1][0] & 0xffff0000u) | bits;
+    };
+    auto read_v = [&](const char* st, int b, int kb, int s2) -> u32x4 {
+        const int koff = (32 * kb + 16 * s2) * RS;
+        int a0 = v_rd + koff + b * 64, a1 = a0 + 8 * RS;
+        if (b == DB - 1) {
+            a0 = v_last_real ? a0 : v_last_const;
+            a1 = v_last_real ? a1 : v_last_const;
+        }
+        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(st + a0));
+        const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(st + a1));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        return u32x4{l2[0], l2[1], h2[0], h2[1]};
+    };
+    auto stage = [&](int t) -> const char* { return smem + (t & (NS - 1)) * STAGE; };
+
+    // ---- prologue: tiles 0..2 on their way, S(0) with its shift
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));      // Q loads complete before any DMA is counted
+    issue_tile(0);
+    if (nt > 1) issue_tile(1);
+    if (nt > 2) issue_tile(2);
+    wait_tiles(nt > 2 ? 2 : nt - 1);                                  // tile 0
+    __builtin_amdgcn_s_waitcnt(0xc07f);                               // lgkmcnt(0): the constant chunks
+    __builtin_amdgcn_s_barrier();
+    f32x16 sa[2], sb[2];
+    if (wave_active) {
+        const int valid0 = qe - qs;
+        if (valid0 >= 64) qk(stage(0), sa, 64, std::false_type{}); else qk(stage(0), sa, valid0, std::true_type{});
+        float d = row_max(sa);
+        if (!(d > -INFINITY)) d = 0.f;
+        set_shift(bf16_round(d));
+        if (valid0 >= 64) qk(stage(0), sa, 64, std::false_type{}); else qk(stage(0), sa, valid0, std::true_type{});
+    }
+
+    // one iteration: consumes sc = S(t) - m, produces sn = S(t+1) - m. KIND 1: tile t+1 is a full tile; 2: generic tail
+    // body (tile t+1 may be ragged or absent)
+    auto step = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], const int t, auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        // outstanding, oldest first: tile t+1 (if any), tile t+2 (if any); tile t+1 must have landed
+        wait_tiles(t + 2 < nt ? 1 : 0);
+        __builtin_amdgcn_s_barrier();     // K(t+1), V(t) visible to all; slot of tile t-1 no longer read by anyone
+        if (t + 3 < nt) issue_tile(t + 3);
+        if (!wave_active) return;
+        const char* sn_st = stage(t + 1);
+        const char* sc_st = stage(t);
+        const bool has_next = KIND == 1 || t + 1 < nt;
+        const int valid_next = qe - (qs + (t + 1) * 64);
+        // phase 1: S(t+1) on the matrix pipe, P(t) = exp2(S(t)) on the vector pipe
+        if constexpr (KIND == 1) qk(sn_st, sn, 64, std::false_type{});
+        else if (has_next) qk(sn_st, sn, valid_next, std::true_type{});
+        u32x4 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    pf[kb][s2][w] = pack_bf2(__builtin_amdgcn_exp2f(sc[kb][8 * s2 + 2 * w]),
+                                             __builtin_amdgcn_exp2f(sc[kb][8 * s2 + 2 * w + 1]));
+        // phase 2: O^T += V(t)^T . P(t)^T on the matrix pipe, the row maximum of S(t+1) on the vector pipe
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, read_v(sc_st, b, kb, s2)),
+                                                                     __builtin_bit_cast(bf16x8, pf[kb][s2]), oacc[b], 0, 0, 0);
+        if (has_next) {
+            const float d = row_max(sn);
+            if (__any(d > RESCALE_THR)) {
+                // rare (wave-uniform): move the reference of the rows that need it; O, now complete up to tile t, is
+                // multiplied by 2^-(m_new - sh) and S(t+1) is simply computed again with the new shift
+                const float m_new = d > RESCALE_THR ? bf16_round(sh + d) : sh;
+                const float al = __builtin_amdgcn_exp2f(sh - m_new);
+#pragma unroll
+                for (int b = 0; b < DB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[b][r] *= al;
+                set_shift(m_new);
+                if constexpr (KIND == 1) qk(sn_st, sn, 64, std::false_type{});
+                else qk(sn_st, sn, valid_next, std::true_type{});
+            }
+        }
+    };
+
+    int t = 0;
+    for (; t + 2 < full_tiles; t += 2) {          // tiles t+1 and t+2 are full
+        step(sa, sb, t, std::integral_constant<int, 1>{});
+        step(sb, sa, t + 1, std::integral_constant<int, 1>{});
+    }
+    for (; t < nt; ++t) {
+        step(sa, sb, t, std::integral_constant<int, 2>{});
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sa[kb] = sb[kb];
+    }
+    if (!wave_active) return;
+
+    constexpr int LB = HD / 32, LR = HD % 32;
+    constexpr int LH = (LR >> 2) & 1, LREG = (LR & 3) + 4 * (LR >> 3);
+    float l = oacc[LB][LREG];
+    l = __shfl(l, r32 + 32 * LH, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    bf16_t* orow = p.O + (long)qrow * p.ldo + head * HD;
+#pragma unroll
+    for (int b = 0; b < DB; ++b) {
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            if (32 * b + 16 * gp >= HD) continue;
+            unsigned e0 = pack_bf2(oacc[b][8 * gp + 0] * inv, oacc[b][8 * gp + 1] * inv);
+            unsigned e1 = pack_bf2(oacc[b][8 * gp + 2] * inv, oacc[b][8 * gp + 3] * inv);
+            unsigned o0 = pack_bf2(oacc[b][8 * gp + 4] * inv, oacc[b][8 * gp + 5] * inv);
+            unsigned o1 = pack_bf2(oacc[b][8 * gp + 6] * inv, oacc[b][8 * gp + 7] * inv);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+            const int d0 = 32 * b + 16 * gp + 8 * h;
+            if (qok && d0 < HD) *reinterpret_cast<u32x4*>(orow + d0) = u32x4{(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
+        }
+    }
+}
+
 }  // namespace
 
 // block-diagonal bf16 attention with pre-scaled Q, hd 72, hq == hkv
@@ -363,6 +662,8 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     p.nseg = a.nseg; p.heads = a.hq; p.nqb = (a.max_seqlen + 127) / 128;
     if ((long)p.nseg * p.heads * p.nqb > 0x7fffffffL) return COGS_E_INVALID;
     dim3 grid(p.nseg * p.heads * p.nqb);
-    hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p);
+    static const int variant = getenv("COGS_ATTN_VIT") ? atoi(getenv("COGS_ATTN_VIT")) : 2;     // 1: unpipelined (A/B runs)
+    if (variant == 1 || a.ldk != a.ldv) hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn_vit_pipe_kernel<72>, grid, dim3(256), 0, st, p);
     return COGS_LAUNCH_CHECK();
 }
