@@ -433,6 +433,11 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     // read carries no memory operand to disambiguate), which would drain the three-tile prefetch every iteration. Hidden
     // vector-memory operations only make the compiler's own vmcnt waits (Q loads, O stores) more conservative.
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto uniform_ptr = [](const bf16_t* q) -> const bf16_t* {      // wave-uniform by construction; tell the compiler
+        const unsigned long long v = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const bf16_t*)(((unsigned long long)hi << 32) | lo);
+    };
     auto dma16 = [&](const bf16_t* base, int off_bytes, unsigned lds) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                      :: "s"(lds), "v"(off_bytes), "s"(base) : "memory");
@@ -440,9 +445,9 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     auto issue_tile = [&](int t) {
         const int kbase = qs + t * 64;
         const int valid = qe - kbase;                            // >= 1
-        const bf16_t* kb = p.K + (long)kbase * p.ldk;
-        const bf16_t* vb = p.V + (long)kbase * p.ldv;
-        const unsigned st = smem_lds + (t & (NS - 1)) * STAGE;
+        const bf16_t* kb = uniform_ptr(p.K + (long)kbase * p.ldk);
+        const bf16_t* vb = uniform_ptr(p.V + (long)kbase * p.ldv);
+        const unsigned st = __builtin_amdgcn_readfirstlane(smem_lds + (t & (NS - 1)) * STAGE);
         int off[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) off[i] = pc_off[i];
@@ -486,40 +491,42 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         for (int r = 0; r < 16; ++r) oacc[b][r] = 0.f;
     float sh = 0.f;
 
-    // S^T - m of one tile into s[2]; MASKED: keys >= valid get -inf
-    auto qk = [&](const char* st, f32x16 (&s)[2], const int valid, auto masked_tag) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
+    // The pipeline runs at 32-key BLOCK granularity (two blocks per tile): block j = tile j >> 1, key half j & 1.
+    //     sub-step j:   P(j) = exp2(S(j))      beside   S(j+1) = K(j+1).Q^T      (5 chained MFMAs)
+    //                   O += V(j)^T.P(j)       beside   max over S(j+1)          (6 MFMAs)
+    // and the LDS fragment reads run one stage ahead of their MFMAs: the V fragments of block j are requested at the
+    // start of sub-step j (consumed in its second phase), the K fragments of block j+2 at the start of its second phase
+    // (consumed in sub-step j+1). Half-tile blocks keep the live set small enough for that (S 2 x 16, P 8, K fragments
+    // 20, V fragments 24 registers): with whole tiles in flight the compiler had no registers left and read every V
+    // fragment right in front of its MFMA -- twelve exposed LDS latencies per tile.
+    const int len = qe - qs;
+    const int nblk = (len + 31) >> 5, nfull = len >> 5;
+    auto read_k = [&](const char* st, int kb, u32x4 (&kf)[KS]) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            u32x4 kf[KS];
+        for (int ks = 0; ks < KS - 1; ++ks) kf[ks] = *reinterpret_cast<const u32x4*>(st + k_rd + kb * 32 * RS + ks * 32);
+        kf[KS - 1] = *reinterpret_cast<const u32x4*>(st + k_last[kb]);
+    };
+    auto qk_blk = [&](const u32x4 (&kf)[KS], f32x16& sx) {
 #pragma unroll
-            for (int ks = 0; ks < KS - 1; ++ks) kf[ks] = *reinterpret_cast<const u32x4*>(st + k_rd + kb * 32 * RS + ks * 32);
-            kf[KS - 1] = *reinterpret_cast<const u32x4*>(st + k_last[kb]);
+        for (int ks = 0; ks < KS; ++ks) {
+            f32x16 c0;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                f32x16 c0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c0[r] = 0.f;
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), __builtin_bit_cast(bf16x8, qf[ks]),
-                                                                ks == 0 ? c0 : s[kb], 0, 0, 0);
-            }
-        }
-        if constexpr (MASKED) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= valid) s[kb][r] = -INFINITY;
-                }
+            for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+            sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), __builtin_bit_cast(bf16x8, qf[ks]),
+                                                         ks == 0 ? c0 : sx, 0, 0, 0);
         }
     };
-    auto row_max = [&](const f32x16 (&s)[2]) -> float {
-        float d = s[0][0];
+    auto mask_blk = [&](f32x16& sx, const int valid) {            // keys >= valid of the block do not exist
 #pragma unroll
-        for (int r = 1; r < 16; ++r) d = fmaxf(d, s[0][r]);
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (key >= valid) sx[r] = -INFINITY;
+        }
+    };
+    auto blk_max = [&](const f32x16& sx) -> float {
+        float d = sx[0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d = fmaxf(d, s[1][r]);
+        for (int r = 1; r < 16; ++r) d = fmaxf(d, sx[r]);
         const unsigned db = __builtin_bit_cast(unsigned, d);
         const auto sw = __builtin_amdgcn_permlane32_swap(db, db, false, false);
         return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     };
     auto stage = [&](int t) -> const char* { return smem + (t & (NS - 1)) * STAGE; };
 
-    // ---- prologue: tiles 0..2 on their way, S(0) with its shift
+    // ---- prologue: tiles 0..2 on their way, S(block 0) with its shift, the K fragments of block 1
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));      // Q loads complete before any DMA is counted
     issue_tile(0);
@@ -552,55 +559,56 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     wait_tiles(nt > 2 ? 2 : nt - 1);                                  // tile 0
     __builtin_amdgcn_s_waitcnt(0xc07f);                               // lgkmcnt(0): the constant chunks
     __builtin_amdgcn_s_barrier();
-    f32x16 sa[2], sb[2];
+    f32x16 sa, sb;
+    u32x4 kf[KS];                                                     // K fragments of the NEXT block to be multiplied
     if (wave_active) {
-        const int valid0 = qe - qs;
-        if (valid0 >= 64) qk(stage(0), sa, 64, std::false_type{}); else qk(stage(0), sa, valid0, std::true_type{});
-        float d = row_max(sa);
+        read_k(stage(0), 0, kf);
+        qk_blk(kf, sa);
+        if (len < 32) mask_blk(sa, len);
+        float d = blk_max(sa);
         if (!(d > -INFINITY)) d = 0.f;
         set_shift(bf16_round(d));
-        if (valid0 >= 64) qk(stage(0), sa, 64, std::false_type{}); else qk(stage(0), sa, valid0, std::true_type{});
+        qk_blk(kf, sa);
+        if (len < 32) mask_blk(sa, len);
+        read_k(stage(0), 1, kf);
     }
 
-    // one iteration: consumes sc = S(t) - m, produces sn = S(t+1) - m. KIND 1: tile t+1 is a full tile; 2: generic tail
-    // body (tile t+1 may be ragged or absent)
-    auto step = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], const int t, auto kind_tag) {
+    // sub-step j: consumes sc = S(j) - m, produces sn = S(j+1) - m from the fragments in kf, leaves the fragments of
+    // block j+2 in kf. KIND 1: block j+1 is full; 3: block j+1 is the ragged last block; 0: j is the last block
+    auto substep = [&](f32x16& sc, f32x16& sn, const int j, auto kind_tag) {
         constexpr int KIND = decltype(kind_tag)::value;
-        // outstanding, oldest first: tile t+1 (if any), tile t+2 (if any); tile t+1 must have landed
-        wait_tiles(t + 2 < nt ? 1 : 0);
-        __builtin_amdgcn_s_barrier();     // K(t+1), V(t) visible to all; slot of tile t-1 no longer read by anyone
-        if (t + 3 < nt) issue_tile(t + 3);
-        if (!wave_active) return;
-        const char* sn_st = stage(t + 1);
-        const char* sc_st = stage(t);
-        const bool has_next = KIND == 1 || t + 1 < nt;
-        const int valid_next = qe - (qs + (t + 1) * 64);
-        // phase 1: S(t+1) on the matrix pipe, P(t) = exp2(S(t)) on the vector pipe
-        if constexpr (KIND == 1) qk(sn_st, sn, 64, std::false_type{});
-        else if (has_next) qk(sn_st, sn, valid_next, std::true_type{});
-        u32x4 pf[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    pf[kb][s2][w] = pack_bf2(__builtin_amdgcn_exp2f(sc[kb][8 * s2 + 2 * w]),
-                                             __builtin_amdgcn_exp2f(sc[kb][8 * s2 + 2 * w + 1]));
-        // phase 2: O^T += V(t)^T . P(t)^T on the matrix pipe, the row maximum of S(t+1) on the vector pipe
+        const char* st_c = stage(j >> 1);
+        u32x4 vf[DB][2];
 #pragma unroll
         for (int b = 0; b < DB; ++b)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int s2 = 0; s2 < 2; ++s2) vf[b][s2] = read_v(st_c, b, j & 1, s2);
+        __builtin_amdgcn_sched_barrier(0);        // the reads stay in front of phase 1 (hipcc sinks them to their uses otherwise)
+        // phase 1
+        if constexpr (KIND != 0) qk_blk(kf, sn);
+        u32x4 pf[2];
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-                    oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, read_v(sc_st, b, kb, s2)),
-                                                                     __builtin_bit_cast(bf16x8, pf[kb][s2]), oacc[b], 0, 0, 0);
-        if (has_next) {
-            const float d = row_max(sn);
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                pf[s2][w] = pack_bf2(__builtin_amdgcn_exp2f(sc[8 * s2 + 2 * w]), __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * w + 1]));
+        // phase 2 (the slot of block j+2 holds landed data whenever that block exists; a stale image otherwise, unused)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KIND != 0) read_k(stage((j + 2) >> 1), (j + 2) & 1, kf);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+                oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[b][s2]), __builtin_bit_cast(bf16x8, pf[s2]),
+                                                                 oacc[b], 0, 0, 0);
+        if constexpr (KIND != 0) {
+            const int valid_next = len - 32 * (j + 1);
+            if constexpr (KIND == 3) mask_blk(sn, valid_next);
+            const float d = blk_max(sn);
             if (__any(d > RESCALE_THR)) {
-                // rare (wave-uniform): move the reference of the rows that need it; O, now complete up to tile t, is
-                // multiplied by 2^-(m_new - sh) and S(t+1) is simply computed again with the new shift
+                // rare (wave-uniform): move the reference of the rows that need it; O, now complete up to block j, is
+                // multiplied by 2^-(m_new - sh) and S(j+1) is simply computed again with the new shift
                 const float m_new = d > RESCALE_THR ? bf16_round(sh + d) : sh;
                 const float al = __builtin_amdgcn_exp2f(sh - m_new);
 #pragma unroll
@@ -608,21 +616,41 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[b][r] *= al;
                 set_shift(m_new);
-                if constexpr (KIND == 1) qk(sn_st, sn, 64, std::false_type{});
-                else qk(sn_st, sn, valid_next, std::true_type{});
+                u32x4 kt[KS];
+                read_k(stage((j + 1) >> 1), (j + 1) & 1, kt);
+                qk_blk(kt, sn);
+                if constexpr (KIND == 3) mask_blk(sn, valid_next);
             }
         }
     };
+    auto tile_head = [&](const int t) {
+        // outstanding, oldest first: tile t+1 (if any), tile t+2 (if any); tile t+1 must have landed
+        wait_tiles(t + 2 < nt ? 1 : 0);
+        __builtin_amdgcn_s_barrier();     // K(t+1), V(t) visible to all; slot of tile t-1 no longer read by anyone
+        if (t + 3 < nt) issue_tile(t + 3);
+    };
 
     int t = 0;
-    for (; t + 2 < full_tiles; t += 2) {          // tiles t+1 and t+2 are full
-        step(sa, sb, t, std::integral_constant<int, 1>{});
-        step(sb, sa, t + 1, std::integral_constant<int, 1>{});
+    for (; 2 * t + 2 < nfull; ++t) {              // blocks 2t+1 and 2t+2 are full
+        tile_head(t);
+        if (wave_active) {
+            substep(sa, sb, 2 * t, std::integral_constant<int, 1>{});
+            substep(sb, sa, 2 * t + 1, std::integral_constant<int, 1>{});
+        }
     }
-    for (; t < nt; ++t) {
-        step(sa, sb, t, std::integral_constant<int, 2>{});
+    for (; t < nt; ++t) {                         // the ragged end: block kinds decided at run time (wave-uniform)
+        tile_head(t);
+        if (!wave_active) continue;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) sa[kb] = sb[kb];
+        for (int kb = 0; kb < 2; ++kb) {
+            const int j = 2 * t + kb;
+            if (j >= nblk) break;
+            f32x16& sc = kb == 0 ? sa : sb;
+            f32x16& sn = kb == 0 ? sb : sa;
+            if (j + 1 < nfull) substep(sc, sn, j, std::integral_constant<int, 1>{});
+            else if (j + 1 < nblk) substep(sc, sn, j, std::integral_constant<int, 3>{});
+            else substep(sc, sn, j, std::integral_constant<int, 0>{});
+        }
     }
     if (!wave_active) return;
 
