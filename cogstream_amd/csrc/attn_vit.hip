@@ -40,8 +40,10 @@ struct VitAttnArgs {
 
 constexpr float RESCALE_THR = 6.0f;
 
-#ifdef COGS_ATTN_STAMPS   // diagnostic build (tools/micro/attn_vit_micro.cpp): where does a tile's time go, wave 0 of workgroup 0
+#if defined(COGS_ATTN_STAMPS) || defined(COGS_PIPE_STAMPS)   // diagnostic builds (tools/micro/attn_vit_micro.cpp)
 __device__ unsigned long long g_attn_stamps[8];
+#endif
+#ifdef COGS_ATTN_STAMPS   // where does a tile's time go, wave 0 of one workgroup
 #define STAMP(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - st_prev; st_prev = now_; } while (0)
 #else
 #define STAMP(acc_) do {} while (0)
@@ -366,9 +368,18 @@ __global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
 //       reads a 2-way conflict on half their lanes. The pad column has no room in that image: the lanes that would
 //       read it (K: k-half 1 of the last k-step; V: the pieces d = 72..95 of the last d-block) are pointed at a
 //       constant chunk [1, 0 x7] / zeros behind the tile instead.
-// S(t) and S(t+1) live in two register sets that swap roles between the halves of a manually unrolled loop pair; the
-// ragged end runs through one generic, copying body. Rows past the segment end are read from its last row (finite
-// data, their scores are masked), never from outside.
+// Rows past the segment end are read from its last row (finite data, their scores are masked), never from outside.
+//
+// Stamped life of a workgroup (cfg2 shape, 15 tiles, -DCOGS_PIPE_STAMPS, shader cycles): 7 500 from kernel entry to "Q
+// and tile 0 landed" (kernel arguments, segment bounds, Q + first tiles: three dependent round trips on a loaded chip),
+// 900 to S(0), 29 000 in the tile loop (1 930 per tile at two workgroups per CU, i.e. 965 per wave and tile on a SIMD
+// against 704 cycles of MFMA and an issue-bound floor near 880), 1 900 for normalise + store. A fifth of its life is the
+// entry, during which its SIMDs hold one wave only. Keeping the K/V stream running across the seam was built three times
+// -- a persistent grid walking all items (also with a rotating item order, so that no workgroup sees only the ragged
+// blocks), the same at 32-key granularity, and 2 or 4 consecutive query blocks of one (frame, head) per workgroup -- and
+// each time the tile loop lost more (hoisted per-item scalars: 60-80 spilled SGPRs, spilled VGPRs whose reloads count
+// on vmcnt; a static item order instead of the dispatcher's dynamic one) than the seam gave back: 0.42-0.44 ms against
+// 0.40 ms per layer in the same run. Removed.
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     constexpr int NT = 256, QB = 128, NS = 4;
@@ -379,11 +390,23 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     constexpr int PIECES = TILE / 1024;               // 9 DMA pieces of 1 KiB per matrix and tile
     static_assert(TILE % 1024 == 0, "a tile is a whole number of 1 KiB pieces");
     constexpr int C_ONE = 2 * TILE, C_ZERO = 2 * TILE + 16, STAGE = 2 * TILE + 64;     // [K | V | one-chunk | zero-chunk | -]
+#ifdef ABL_ONE_WG      // ablation (tools/attn_abl.sh): one workgroup per CU -- the LDS request no longer fits twice
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + 16384];
+#else
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, r32 = lane & 31;
+#ifdef COGS_PIPE_STAMPS     // diagnostic build (tools/micro/attn_vit_micro.cpp): life of one workgroup (wave 0) in shader cycles
+    unsigned long long ps_t[8];
+    int ps_n = 0;
+#define PSTAMP() do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); ps_t[ps_n++] = t_; } while (0)
+#else
+#define PSTAMP() do {} while (0)
+#endif
+    PSTAMP();      // 0: kernel entry
     int seg, head, qb;
     {
         const int nhf = p.nseg * p.heads, id = blockIdx.x;      // XCD-aware order, see attn_vit_kernel
@@ -558,6 +581,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     if (nt > 2) issue_tile(2);
     wait_tiles(nt > 2 ? 2 : nt - 1);                                  // tile 0
     __builtin_amdgcn_s_waitcnt(0xc07f);                               // lgkmcnt(0): the constant chunks
+    PSTAMP();      // 1: Q and tile 0 landed
     __builtin_amdgcn_s_barrier();
     f32x16 sa, sb;
     u32x4 kf[KS];                                                     // K fragments of the NEXT block to be multiplied
@@ -627,17 +651,23 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         // outstanding, oldest first: tile t+1 (if any), tile t+2 (if any); tile t+1 must have landed
         wait_tiles(t + 2 < nt ? 1 : 0);
         __builtin_amdgcn_s_barrier();     // K(t+1), V(t) visible to all; slot of tile t-1 no longer read by anyone
+#ifndef ABL_NOLOAD
         if (t + 3 < nt) issue_tile(t + 3);
+#endif
     };
 
+    PSTAMP();      // 2: S(0) ready
     int t = 0;
     for (; 2 * t + 2 < nfull; ++t) {              // blocks 2t+1 and 2t+2 are full
         tile_head(t);
+#ifndef ABL_NOCOMPUTE
         if (wave_active) {
             substep(sa, sb, 2 * t, std::integral_constant<int, 1>{});
             substep(sb, sa, 2 * t + 1, std::integral_constant<int, 1>{});
         }
+#endif
     }
+    PSTAMP();      // 3: main loop done
     for (; t < nt; ++t) {                         // the ragged end: block kinds decided at run time (wave-uniform)
         tile_head(t);
         if (!wave_active) continue;
@@ -652,6 +682,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             else substep(sc, sn, j, std::integral_constant<int, 0>{});
         }
     }
+    PSTAMP();      // 4: tail done
     if (!wave_active) return;
 
     constexpr int LB = HD / 32, LR = HD % 32;
@@ -675,6 +706,11 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             if (qok && d0 < HD) *reinterpret_cast<u32x4*>(orow + d0) = u32x4{(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
         }
     }
+#ifdef COGS_PIPE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PSTAMP();      // 5: O stored
+    if (blockIdx.x == 3000 && tid == 0) { for (int i = 0; i < 6; ++i) g_attn_stamps[i] = ps_t[i]; g_attn_stamps[6] = nt; }
+#endif
 }
 
 }  // namespace

@@ -42,5 +42,13 @@ int main(int argc, char** argv) {
     printf("per full tile, wave 0 of one workgroup (cycles): barrier wait %.0f | stage %.0f | QK (to results) %.0f | softmax %.0f | PV issue %.0f | sum %.0f\n",
            st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, (st[0] + st[1] + st[2] + st[3] + st[4]) / n);
 #endif
+#ifdef COGS_PIPE_STAMPS
+    {
+        unsigned long long st[8];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_attn_stamps), sizeof(st));
+        printf("workgroup 3000, wave 0 (ticks of s_memtime, 100 MHz -> x ~19 for shader cycles at 1.9 GHz): entry->tile0 landed %llu | ->S(0) ready %llu | main loop %llu (%llu tiles total) | tail %llu | epilogue+store %llu\n",
+               st[1] - st[0], st[2] - st[1], st[3] - st[2], st[6], st[4] - st[3], st[5] - st[4]);
+    }
+#endif
     return 0;
 }
