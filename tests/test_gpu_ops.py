@@ -217,6 +217,50 @@ def test_attention_prescaled_q_block_diag(dev, hd, heads, lens):
     assert rel_err(out.float(), ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("heads,lens", [
+    (1, [1]), (1, [31]), (2, [32, 33]), (1, [63, 64, 65]), (2, [96, 127, 128, 129]), (1, [160, 191, 192, 193]),
+    (8, [200] * 5), (2, [255, 256, 257]), (1, [320, 384, 449]), (8, [924, 924]), (3, [1024, 70, 1000]), (16, [130] * 4)])
+@pytest.mark.parametrize("data", ["random", "ramp"])
+def test_attention_vit_pipeline_edges(dev, heads, lens, data):
+    """The encoder's production attention kernel (csrc/attn_vit.hip: hd 72, per-frame segments, pre-scaled Q,
+    software-pipelined at 32-key blocks with a 4-slot LDS-DMA ring) over every seam of its control flow: segments
+    shorter than a block / a tile / the three-tile prologue, ragged and exactly-full last blocks and tiles, ragged and
+    empty query blocks (waves that only stage), both workgroup orders (frames x heads a multiple of 8 or not).
+    "ramp": the scores of every row GROW along the keys by ~2 log2 units per key block, so the deferred maximum is
+    moved (O rescaled, the block's scores recomputed) again and again in steady state, and one row sits far below
+    zero. Checked row by row against the fp32 softmax of the same bf16 inputs."""
+    ops = _ops()
+    hd, H = 72, heads * 72
+    n = sum(lens)
+    g = torch.Generator().manual_seed(1000 * heads + n + (data == "ramp"))
+    qkv = torch.randn(n, 3 * H, generator=g)
+    qkv[:, :H] *= LOG2E / math.sqrt(hd)
+    if data == "ramp":
+        # q = a common direction u (scaled), k = u * (position in the segment / 16): score ~ 1.5 * pos / 16 log2 units
+        u = torch.randn(hd, generator=g)
+        u /= u.norm()
+        pos = torch.cat([torch.arange(L, dtype=torch.float32) for L in lens])
+        for hh in range(heads):
+            qkv[:, hh * hd:(hh + 1) * hd] += 1.5 * u
+            qkv[:, H + hh * hd:H + (hh + 1) * hd] += u * (pos[:, None] / 16.0)
+        qkv[n // 2, :H] = -3.0 * u.repeat(heads)          # a row whose scores fall with the key index
+    qkv = qkv.bfloat16()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    ref = _attn_ref(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], heads, heads, hd, cu=cu.long(), scale=math.log(2.0))
+    gq = qkv.to(dev)
+    out = ops.attention(gq[:, :H], gq[:, H:2 * H], gq[:, 2 * H:], hq=heads, hkv=heads, head_dim=hd,
+                        cu_seqlens=cu.to(dev), max_seqlen=max(lens), q_prescaled=True).float().cpu()
+    assert torch.isfinite(out).all()
+    # per row: error against the row's own largest output (a dropped or doubled block shows up at 1e-1 .. 1)
+    err = (out - ref).abs().view(n, heads, hd).amax(2) / ref.abs().view(n, heads, hd).amax(2).clamp_min(1e-3)
+    assert float(err.max()) < 3e-2, (float(err.max()), int(err.argmax()) // heads)
+    # convexity: every output lies inside the range its segment's V spans
+    v = qkv[:, 2 * H:].float()
+    for i, L in enumerate(lens):
+        a, b = int(cu[i]), int(cu[i + 1])
+        assert (out[a:b] <= v[a:b].amax(0) + 2e-2).all() and (out[a:b] >= v[a:b].amin(0) - 2e-2).all()
+
+
 @pytest.mark.parametrize("S,pos0", [(200, 0), (130, 77), (1, 300), (1, 5000)])
 def test_attention_prescaled_q_causal_gqa(dev, S, pos0):
     ops = _ops()
