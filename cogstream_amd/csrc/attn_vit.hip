@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, r32 = lane & 31;
 #ifdef COGS_PIPE_STAMPS     // diagnostic build (tools/micro/attn_vit_micro.cpp): life of one workgroup (wave 0) in shader cycles
-    unsigned long long ps_t[8];
+    unsigned long long ps_t[10];
     int ps_n = 0;
 #define PSTAMP() do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); ps_t[ps_n++] = t_; } while (0)
 #else
@@ -421,6 +421,10 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     }
     const int qs = p.cu[seg], qe = p.cu[seg + 1];
     const int q0 = qs + qb * QB;
+#ifdef COGS_PIPE_STAMPS2
+    asm volatile("" :: "s"(qs), "s"(qe));
+    PSTAMP();      // segment bounds here
+#endif
     if (q0 >= qe) return;
     const int nt = (qe - qs + 63) >> 6;
     const int full_tiles = (qe - qs) >> 6;
@@ -574,12 +578,22 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     auto stage = [&](int t) -> const char* { return smem + (t & (NS - 1)) * STAGE; };
 
     // ---- prologue: tiles 0..2 on their way, S(block 0) with its shift, the K fragments of block 1
-#pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));      // Q loads complete before any DMA is counted
+    // (the Q loads and the first three tiles share one memory round trip: the DMA goes out behind the Q loads, and the
+    // compiler's own wait for Q -- a vmcnt(0), it cannot see the DMA -- covers the tiles as well. Stamped entry of a
+    // workgroup with Q waited for first: 700-1 700 cycles to the segment bounds, 800 of address setup, 1 300-1 900 for
+    // Q, 3 700-4 600 for issuing three tiles and landing the first)
+#ifdef COGS_PIPE_STAMPS2
+    PSTAMP();      // Q loads issued
+#endif
     issue_tile(0);
     if (nt > 1) issue_tile(1);
     if (nt > 2) issue_tile(2);
-    wait_tiles(nt > 2 ? 2 : nt - 1);                                  // tile 0
+#ifdef COGS_PIPE_STAMPS2
+    PSTAMP();      // tiles issued
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));      // Q loads complete before the loop (see attn_vit_kernel)
     __builtin_amdgcn_s_waitcnt(0xc07f);                               // lgkmcnt(0): the constant chunks
     PSTAMP();      // 1: Q and tile 0 landed
     __builtin_amdgcn_s_barrier();
@@ -709,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #ifdef COGS_PIPE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PSTAMP();      // 5: O stored
-    if (blockIdx.x == 3000 && tid == 0) { for (int i = 0; i < 6; ++i) g_attn_stamps[i] = ps_t[i]; g_attn_stamps[6] = nt; }
+    if (blockIdx.x == 3000 && tid == 0) { for (int i = 0; i < 8; ++i) g_attn_stamps[i] = ps_t[i]; }
 #endif
 }
 

@@ -46,8 +46,13 @@ int main(int argc, char** argv) {
     {
         unsigned long long st[8];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(g_attn_stamps), sizeof(st));
-        printf("workgroup 3000, wave 0 (ticks of s_memtime, 100 MHz -> x ~19 for shader cycles at 1.9 GHz): entry->tile0 landed %llu | ->S(0) ready %llu | main loop %llu (%llu tiles total) | tail %llu | epilogue+store %llu\n",
-               st[1] - st[0], st[2] - st[1], st[3] - st[2], st[6], st[4] - st[3], st[5] - st[4]);
+#ifdef COGS_PIPE_STAMPS2
+        printf("workgroup 3000, wave 0 (shader cycles): entry->segment bounds %llu | ->Q loads issued %llu | ->3 tiles issued %llu | ->Q and tiles landed %llu | ->S(0) ready %llu | main loop %llu | tail %llu\n",
+               st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6]);
+#else
+        printf("workgroup 3000, wave 0 (shader cycles): entry->Q and tile 0 landed %llu | ->S(0) ready %llu | main loop %llu | tail %llu | epilogue+store %llu\n",
+               st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4]);
+#endif
     }
 #endif
     return 0;
