@@ -613,9 +613,16 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 
     // sub-step j: consumes sc = S(j) - m, produces sn = S(j+1) - m from the fragments in kf, leaves the fragments of
     // block j+2 in kf. KIND 1: block j+1 is full; 3: block j+1 is the ragged last block; 0: j is the last block
-    auto substep = [&](f32x16& sc, f32x16& sn, const int j, auto kind_tag) {
+    // SLOT >= 0: the ring slot of tile j >> 1 is known at compile time (the four-tile unrolled main loop), so every LDS
+    // address below is a lane-constant register plus an immediate; -1: computed from j
+    auto substep = [&](f32x16& sc, f32x16& sn, const int j, auto kind_tag, auto slot_tag) {
         constexpr int KIND = decltype(kind_tag)::value;
-        const char* st_c = stage(j >> 1);
+        constexpr int SLOT = decltype(slot_tag)::value;
+        auto stage_of = [&](int jb) -> const char* {              // jb in {j, j+1, j+2}: at most one tile ahead of j's
+            if constexpr (SLOT >= 0) return smem + ((SLOT + ((jb >> 1) - (j >> 1))) & (NS - 1)) * STAGE;
+            else return stage(jb >> 1);
+        };
+        const char* st_c = stage_of(j);
         u32x4 vf[DB][2];
 #pragma unroll
         for (int b = 0; b < DB; ++b)
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
                 pf[s2][w] = pack_bf2(__builtin_amdgcn_exp2f(sc[8 * s2 + 2 * w]), __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * w + 1]));
         // phase 2 (the slot of block j+2 holds landed data whenever that block exists; a stale image otherwise, unused)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (KIND != 0) read_k(stage((j + 2) >> 1), (j + 2) & 1, kf);
+        if constexpr (KIND != 0) read_k(stage_of(j + 2), (j + 2) & 1, kf);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
                     for (int r = 0; r < 16; ++r) oacc[b][r] *= al;
                 set_shift(m_new);
                 u32x4 kt[KS];
-                read_k(stage((j + 1) >> 1), (j + 1) & 1, kt);
+                read_k(stage_of(j + 1), (j + 1) & 1, kt);
                 qk_blk(kt, sn);
                 if constexpr (KIND == 3) mask_blk(sn, valid_next);
             }
@@ -672,12 +679,26 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 
     PSTAMP();      // 2: S(0) ready
     int t = 0;
+    using Full = std::integral_constant<int, 1>;
+#ifndef AV_NO_UNROLL4
+    // four tiles per trip: t is a multiple of 4 here, so tile t + i sits in ring slot i (compile-time LDS addresses)
+    for (; 2 * (t + 3) + 2 < nfull; t += 4) {
+#define COGS_AV_TILE(I)                                                                                      \
+        tile_head(t + I);                                                                                    \
+        if (wave_active) {                                                                                   \
+            substep(sa, sb, 2 * (t + I), Full{}, std::integral_constant<int, I>{});                          \
+            substep(sb, sa, 2 * (t + I) + 1, Full{}, std::integral_constant<int, I>{});                      \
+        }
+        COGS_AV_TILE(0) COGS_AV_TILE(1) COGS_AV_TILE(2) COGS_AV_TILE(3)
+#undef COGS_AV_TILE
+    }
+#endif
     for (; 2 * t + 2 < nfull; ++t) {              // blocks 2t+1 and 2t+2 are full
         tile_head(t);
 #ifndef ABL_NOCOMPUTE
         if (wave_active) {
-            substep(sa, sb, 2 * t, std::integral_constant<int, 1>{});
-            substep(sb, sa, 2 * t + 1, std::integral_constant<int, 1>{});
+            substep(sa, sb, 2 * t, Full{}, std::integral_constant<int, -1>{});
+            substep(sb, sa, 2 * t + 1, Full{}, std::integral_constant<int, -1>{});
         }
 #endif
     }
@@ -691,9 +712,9 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             if (j >= nblk) break;
             f32x16& sc = kb == 0 ? sa : sb;
             f32x16& sn = kb == 0 ? sb : sa;
-            if (j + 1 < nfull) substep(sc, sn, j, std::integral_constant<int, 1>{});
-            else if (j + 1 < nblk) substep(sc, sn, j, std::integral_constant<int, 3>{});
-            else substep(sc, sn, j, std::integral_constant<int, 0>{});
+            if (j + 1 < nfull) substep(sc, sn, j, Full{}, std::integral_constant<int, -1>{});
+            else if (j + 1 < nblk) substep(sc, sn, j, std::integral_constant<int, 3>{}, std::integral_constant<int, -1>{});
+            else substep(sc, sn, j, std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{});
         }
     }
     PSTAMP();      // 4: tail done
