@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Default library vs cogstream_amd/libcogs_hip_alt.so (tools/build_alt.sh) on the plain bf16 GEMM shapes of the path,
+interleaved in one process; results must be bit-identical."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cogstream_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+alt = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cogstream_amd", "libcogs_hip_alt.so"))
+shapes = [("ViT qkv", 59136, 3456, 1152), ("ViT o", 59136, 1152, 1152), ("ViT fc1", 59136, 4352, 1152), ("ViT fc2", 59136, 1152, 4352),
+          ("Qwen2 qkv", 15396, 4608, 3584), ("Qwen2 o", 15396, 3584, 3584), ("Qwen2 gate/up", 15396, 37888, 3584),
+          ("Qwen2 down", 15396, 3584, 18944)]
+for name, M, N, K in shapes:
+    a = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
+    w = ((torch.rand(N, K, device=dev) * 2 - 1) * 0.05).bfloat16()
+    bias = torch.rand(N, device=dev).bfloat16()
+    outs, ts = {}, {"default": [], "alt": []}
+    for r in range(7):
+        for tag, lib in (("default", None), ("alt", alt)):
+            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.gemm(a, w, bias=bias, out=out, lib=lib)
+            e1.record()
+            torch.cuda.synchronize()
+            if r:
+                ts[tag].append(e0.elapsed_time(e1))
+            outs[tag] = out
+    same = bool(torch.equal(outs["default"], outs["alt"]))
+    md, ma = sorted(ts["default"])[3], sorted(ts["alt"])[3]
+    fl = 2.0 * M * N * K
+    print(f"{name:14s} {M}x{N}x{K}: default {md:.3f} ms {fl / md / 1e9:6.0f} TF | alt {ma:.3f} ms {fl / ma / 1e9:6.0f} TF | alt/default {ma / md:.3f} | bit-identical {same}")
