@@ -38,6 +38,17 @@ __device__ __forceinline__ void rms_apply(float (&x)[E], const T* gamma, float r
     }
 }
 
+// the same on 8 values with gamma already in registers (bf16 path of the register-resident prologue below)
+__device__ __forceinline__ void rms_apply_reg(float (&x)[8], const float (&g)[8], float rstd) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float n = x[e] * rstd;
+        n = bf2f(f2bf(n));
+        n = g[e] * n;
+        x[e] = bf2f(f2bf(n));
+    }
+}
+
 // epilogue of 2 consecutive output columns n, n+1 (one rotary / SwiGLU pair): same arithmetic as epilogue4
 template <typename T>
 __device__ __forceinline__ void epilogue2(const EpiArgs& p, int n, float v0, float v1) {
@@ -95,6 +106,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
             for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(raw[i]);
         }
     };
+    // Weights are read exactly once per token by exactly one CU: non-temporal loads keep them from displacing what IS
+    // re-read (x, the KV cache, the next kernels' operands) in L2 / the Infinity Cache (A/B: COGS_GEMV_NT=0 at build time)
+    auto ldw = [](const T* q) -> u32x4 {
+#ifndef COGS_GEMV_NO_NT
+        return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q));
+#else
+        return *reinterpret_cast<const u32x4*>(q);
+#endif
+    };
     // The first batch of weight chunks is requested BEFORE the fused RMSNorm statistics: the weights do not depend
     // on x, and the statistics (a dependent load -> reduce -> rsqrt chain, ~2 us) would otherwise sit in front of the
     // whole stream (the qkv GEMV took 14.8 us against 8.0 us for the o projection of nearly the same size).
@@ -105,9 +125,73 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int r = 0; r < R; ++r) w_first[u][r] = *reinterpret_cast<const u32x4*>(w[r] + (ch + 64 * u) * EPC);
+            for (int r = 0; r < R; ++r) w_first[u][r] = ldw(w[r] + (ch + 64 * u) * EPC);
     }
     float rstd = 1.f;
+    // Fused Qwen2RMSNorm with K = 3584 (every fused call of the model: qkv, gate/up, lm_head): x and gamma are 7 chunks
+    // per lane, loaded ONCE into registers right behind the first weight batch and used for the statistics and for the
+    // products (the generic path below reads x twice and gamma once more, from L2, inside the dependent chain: the
+    // prologue cost 4.3 us of a 12.9 us qkv call). Same summation order as the generic path: bit-identical results.
+    constexpr int XC = 7;
+    if constexpr (sizeof(T) == 2) {
+        if (gam && nch == XC * 64) {
+            u32x4 xall[XC], gall[XC];
+#pragma unroll
+            for (int i = 0; i < XC; ++i) {
+                xall[i] = *reinterpret_cast<const u32x4*>(x + (lane + 64 * i) * EPC);
+                gall[i] = *reinterpret_cast<const u32x4*>(gam + (lane + 64 * i) * EPC);
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < XC; ++i) {
+                float xv[EPC];
+                to_f(xall[i], xv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) ss += xv[e] * xv[e];
+            }
+            ss = wave_sum(ss);
+            rstd = rsqrtf(ss / (float)p.K + p.rms_eps);
+            float accr[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) accr[r] = 0.f;
+#pragma unroll
+            for (int b0 = 0; b0 < XC; b0 += U) {
+                constexpr int dummy = 0; (void)dummy;
+                u32x4 wr[U][R];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (b0 + u < XC) wr[u][r] = b0 == 0 ? w_first[u][r] : ldw(w[r] + (lane + 64 * (b0 + u)) * EPC);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (b0 + u >= XC) continue;
+                    float xa[EPC], ga[EPC];
+                    to_f(xall[b0 + u], xa);
+                    to_f(gall[b0 + u], ga);
+                    rms_apply_reg(reinterpret_cast<float(&)[8]>(xa), reinterpret_cast<const float(&)[8]>(ga), rstd);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float wa[EPC];
+                        to_f(wr[u][r], wa);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) accr[r] += wa[e] * xa[e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) accr[r] = wave_sum(accr[r]);
+            if (lane == 0) {
+                EpiArgs e = p.epi;
+                if (p.kv_k && n >= p.kv_col0)
+                    e.C = (n < p.kv_col0 + p.kv_dim) ? p.kv_k - (long)p.kv_col0 * sizeof(T)
+                                                     : p.kv_v - (long)(p.kv_col0 + p.kv_dim) * sizeof(T);
+                if constexpr (R == 4) epilogue4<T>(e, 0, n, f32x4{accr[0], accr[1], accr[2], accr[3]});
+                else epilogue2<T>(e, n, accr[0], accr[1]);
+            }
+            return;
+        }
+    }
     if (gam) {
         // every wave covers the whole x with its 64 lanes: the statistics need no LDS and no barrier
         float ss = 0.f;
@@ -149,7 +233,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int r = 0; r < R; ++r) wr[u][r] = *reinterpret_cast<const u32x4*>(w[r] + (ch + 64 * u) * EPC);
+            for (int r = 0; r < R; ++r) wr[u][r] = ldw(w[r] + (ch + 64 * u) * EPC);
 #pragma unroll
         for (int u = 0; u < U; ++u) xr[u] = *reinterpret_cast<const u32x4*>(x + (ch + 64 * u) * EPC);
 #pragma unroll
@@ -169,7 +253,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
     for (; ch < nch; ch += 64) {
         u32x4 wr[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) wr[r] = *reinterpret_cast<const u32x4*>(w[r] + ch * EPC);
+        for (int r = 0; r < R; ++r) wr[r] = ldw(w[r] + ch * EPC);
         float xa[EPC];
         to_f(*reinterpret_cast<const u32x4*>(x + ch * EPC), xa);
         if (gam) rms_apply<T, EPC>(xa, gam + ch * EPC, rstd);

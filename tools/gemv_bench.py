@@ -11,6 +11,10 @@ from cogstream_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 bf = torch.bfloat16
+ALT = None
+if os.environ.get("COGS_ALT_LIB") == "1":      # tools/build_alt.sh gemv <flags>: time that build instead
+    import ctypes
+    ALT = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cogstream_amd", "libcogs_hip_alt.so"))
 H, I, V = 3584, 18944, 152064
 shapes = [("qkv  N4608  K3584", 4608, H, {}), ("o    N3584  K3584 +res", H, H, {"res": True}),
           ("gu   N37888 K3584 swiglu", 2 * I, H, {"act": L.ACT_SWIGLU}), ("down N3584  K18944 +res", H, I, {"res": True}),
@@ -35,7 +39,7 @@ for r in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(REP):                      # back to back, as inside a decode step
-            ops.gemm(x, ws[(r * REP + i) % len(ws)], **args)
+            ops.gemm(x, ws[(r * REP + i) % len(ws)], lib=ALT, **args)
         e1.record()
         torch.cuda.synchronize()
         if r > 0:
