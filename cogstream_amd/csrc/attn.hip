@@ -186,7 +186,17 @@ __global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : ((PRE && HD == 72) ? 
         const int kbase = ks + kt * 64;
         const bf16_t* kb = Kp + (long)kbase * p.ldk;
         const bf16_t* vb = Vp + (long)kbase * p.ldv;
-        if (kbase + 64 <= ke) {
+        if (kbase + 64 <= ke && p.gqa_pack) {
+            // single-token decode: every K/V byte is read once per token by one workgroup -- non-temporal, so that the
+            // cache rows do not displace what the step re-reads (the same change took 5-10 % off the weight-streaming GEMVs)
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                if (i + 1 < PER || NCH % NT == 0 || st_ok[i]) {
+                    kreg[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + k_goff[i]));
+                    vreg[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + v_goff[i]));
+                }
+            }
+        } else if (kbase + 64 <= ke) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 if (i + 1 < PER || NCH % NT == 0 || st_ok[i]) {

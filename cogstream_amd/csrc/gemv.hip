@@ -10,6 +10,13 @@
 #include "kernels.h"
 #include "gemm_epilogue.h"
 
+#ifndef GEMV_U_SMALL
+#define GEMV_U_SMALL 4
+#endif
+#ifndef GEMV_U_BIG
+#define GEMV_U_BIG 2
+#endif
+
 namespace {
 
 struct GemvArgs {
@@ -295,11 +302,11 @@ int cogs_k_gemv(hipStream_t st, const CogsGemm& g) {
     const bool small_n = g.N / 16 < 1024;
     if (small_n) {
         const int grid = (g.N / 2 + 3) / 4;
-        if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL((gemv_kernel<bf16_t, 2, 4>), dim3(grid), dim3(256), 0, st, p);
+        if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL((gemv_kernel<bf16_t, 2, GEMV_U_SMALL>), dim3(grid), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemv_kernel<float, 2, 4>), dim3(grid), dim3(256), 0, st, p);
     } else {
         const int grid = (g.N / 4 + 3) / 4;
-        if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL((gemv_kernel<bf16_t, 4, 2>), dim3(grid), dim3(256), 0, st, p);
+        if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL((gemv_kernel<bf16_t, 4, GEMV_U_BIG>), dim3(grid), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemv_kernel<float, 4, 2>), dim3(grid), dim3(256), 0, st, p);
     }
     return COGS_LAUNCH_CHECK();
