@@ -178,28 +178,37 @@ __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __re
         }
     }
     __syncthreads();
-    if (tid != 0) return;
     const int m = min(m0 + ties_sh, KEPT_MAX);
-    if (m == 0) { out_token[0] = 0; if (n_kept) n_kept[0] = 0; return; }
-    // probabilities of the kept scores (softmax over the row with everything else at -inf), fp32 like torch
+    if (m == 0) { if (tid == 0) { out_token[0] = 0; if (n_kept) n_kept[0] = 0; } return; }
+    // exp and the exponential draw of every kept candidate in parallel (a Philox draw is ~100 instructions: done one
+    // after the other by thread 0 they were most of this kernel's 72 us); the sums below keep their sequential order,
+    // so every result is bit for bit what the single-threaded tail produced
+    __shared__ float ev[KEPT_MAX], qv[KEPT_MAX];
     const float mx = fkey_inv(sk[0]);
+    for (int j = tid; j < m; j += 1024) {
+        ev[j] = expf(fkey_inv(sk[j]) - mx);
+        qv[j] = draw_q(draws, seed, offset, si[j]);
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    // probabilities of the kept scores (softmax over the row with everything else at -inf), fp32 like torch
     float sum = 0.f;
-    for (int j = 0; j < m; ++j) sum += expf(fkey_inv(sk[j]) - mx);
+    for (int j = 0; j < m; ++j) sum += ev[j];
     int keep = m;   // entries 0..keep-1 survive top-p (they are in descending order)
     if (lim > 0.0f) {
         float cum = 0.f;
         for (int j = m - 1; j >= 1; --j) {
-            cum += expf(fkey_inv(sk[j]) - mx) / sum;
+            cum += ev[j] / sum;
             if (cum <= lim) keep = j; else break;
         }
     }
     float sum2 = 0.f;
-    for (int j = 0; j < keep; ++j) sum2 += expf(fkey_inv(sk[j]) - mx);
+    for (int j = 0; j < keep; ++j) sum2 += ev[j];
     float best = -1.f;
     int best_i = si[0];
     for (int j = 0; j < keep; ++j) {
-        const float p = expf(fkey_inv(sk[j]) - mx) / sum2;
-        const float sc = p / draw_q(draws, seed, offset, si[j]);
+        const float p = ev[j] / sum2;
+        const float sc = p / qv[j];
         if (sc > best || (sc == best && si[j] < best_i)) { best = sc; best_i = si[j]; }
         if (kept_idx && j < kept_cap) { kept_idx[j] = si[j]; kept_prob[j] = p; }
     }
