@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Decode GEMV timing per Qwen2-7B shape (HIP events, interleaved rounds, weights rotated through > L2+MALL)."""
+"""Decode GEMV timing per Qwen2-7B shape (HIP events, interleaved rounds, weights rotated through > L2+MALL).
+NOTE: every call goes through Python + ctypes (~12 us), so shapes that take less than that (qkv, o) read as ~12 us whatever
+the kernel does; use tools/micro/gemv_micro.cpp (launches from C++) or a rocprofv3 trace for those."""
 import os
 import sys
 
