@@ -38,6 +38,7 @@ struct AttnArgs {
     float bias_log2;                // additive same-segment bias * log2(e)
     int q_pos0;                     // causal: key j visible to query i iff j <= i + q_pos0
     int causal;
+    int heavy_first;                // causal, one sequence: query tiles in descending order
     int nsplit;                     // >1: keys split over blocks, partials go to part_o/part_ml
     int gqa_pack;                   // decode: the q-heads of one kv head are the 16 query columns
     int q_prescaled;                // Q already carries scale*log2(e): use the PRE kernels
@@ -92,7 +93,9 @@ __global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : ((PRE && HD == 72) ? 
 
     int qs = 0, qe = p.q_len, ks = 0, ke = p.kv_len;
     if (p.cu) { qs = p.cu[seg]; qe = p.cu[seg + 1]; ks = qs; ke = qe; }
-    const int q0 = qs + (blockIdx.x / p.nsplit) * 128;
+    // causal prompts: the late (long) query tiles of a head are issued first, the short ones fill the tail of the launch
+    const int qt = p.heavy_first ? (int)(gridDim.x / p.nsplit) - 1 - (int)(blockIdx.x / p.nsplit) : (int)(blockIdx.x / p.nsplit);
+    const int q0 = qs + qt * 128;
     if (q0 >= qe) return;
 
     const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q);
@@ -619,6 +622,8 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
     p.q_pos0 = a.q_pos0; p.causal = a.causal;
     const int nseg = a.cu_seqlens ? a.nseg : 1;
     p.nsplit = 1; p.gqa_pack = 0; p.q_prescaled = 0; p.part_o = nullptr; p.part_ml = nullptr;
+    static const bool env_light_first = getenv("COGS_ATTN_LIGHT_FIRST") && atoi(getenv("COGS_ATTN_LIGHT_FIRST")) == 1;   // A/B runs only
+    p.heavy_first = (a.causal && !a.cu_seqlens && a.q_len > 128 && !env_light_first) ? 1 : 0;
     // the encoder's production shape (per-frame segments, hd 72, pre-scaled Q, no masks) has its own kernel
     static const bool env_old_vit = getenv("COGS_ATTN_VIT") && atoi(getenv("COGS_ATTN_VIT")) == 0;   // A/B runs only
     if (a.dtype == COGS_DT_BF16 && !a.force_rowwise && a.head_dim == 72 && a.q_prescaled && a.cu_seqlens && !a.row_lo &&
