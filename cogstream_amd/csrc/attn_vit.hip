@@ -465,6 +465,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return (const bf16_t*)(((unsigned long long)hi << 32) | lo);
     };
+    // (M0 is a reserved register for hipcc: it never keeps a value there across statements and sets it right in front
+    // of its own uses, so writing it here needs no clobber -- naming it in the clobber list only draws a warning)
     auto dma16 = [&](const bf16_t* base, int off_bytes, unsigned lds) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                      :: "s"(lds), "v"(off_bytes), "s"(base) : "memory");
