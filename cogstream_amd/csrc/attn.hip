@@ -658,7 +658,12 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
         if (pre) hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD_, NQ_, true>), grid, dim3(NT_), 0, st, p);          \
         else hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD_, NQ_, false>), grid, dim3(NT_), 0, st, p);             \
     } while (0)
-        if (a.head_dim == 72) {
+        // the generated tokens' attention (one query row, key-split) has its own kernel: every wave owns whole tiles
+        static const bool env_old_dec = getenv("COGS_ATTN_DECODE") && atoi(getenv("COGS_ATTN_DECODE")) == 0;   // A/B runs only
+        if (a.head_dim == 128 && a.q_len == 1 && p.nsplit > 1 && p.gqa_pack && pre && !env_old_dec) {
+            const int rc = cogs_k_attention_decode(st, a, p.part_o, p.part_ml);
+            if (rc != COGS_OK) return rc;
+        } else if (a.head_dim == 72) {
             if (light && !p.gqa_pack) COGS_ATTN_LAUNCH(72, 1, 512);
             else COGS_ATTN_LAUNCH(72, 2, 256);
         } else {

@@ -72,6 +72,7 @@ struct CogsAttn {
     int q_prescaled = 0;              // Q already multiplied by scale*log2(e) (bf16 MFMA kernels only; no bias mode)
 };
 int cogs_k_attention_vit(hipStream_t st, const struct CogsAttn& a);   // attn_vit.hip: block-diagonal, hd 72, pre-scaled Q
+int cogs_k_attention_decode(hipStream_t st, const struct CogsAttn& a, float* part_o, float* part_ml);   // attn_decode.hip: one query row, hd 128, key-split partials
 int cogs_k_attention(hipStream_t st, const CogsAttn& a);
 long cogs_k_gemm_launch_count();   // kernels launched by cogs_k_gemm so far on this thread
 
