@@ -653,17 +653,21 @@ static cogs_status llm_forward_impl(cogs_handle h, cogs_stream stream, const voi
         { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_seg_positions(st, cu_d, nseg, pos_d)); }
     }
 
-    if (hipMemcpyAsync(x, embeds, (size_t)S * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return COGS_E_HIP;
+    // single-token decode reads the new embedding row in place (layer 0's qkv input and residual source), everything
+    // else copies the prompt rows into the residual stream first
+    const bool embeds_in_place = (S == 1 && nseg == 0);
+    if (!embeds_in_place && hipMemcpyAsync(x, embeds, (size_t)S * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return COGS_E_HIP;
     { PROF(COGS_PROF_OTHER); COGS_TRY(cogs_k_llm_rope_table(st, rc, rs, nseg > 0 ? pos_d : nullptr, pos0, S, h->llm_inv_freq, hd / 2)); }
     const float scale = 1.0f / sqrtf((float)hd);
     const bool prescale_q = dt == COGS_DT_BF16 && hd == 128;   // see cogs_vit_encode
     for (int l = 0; l < w.layers; ++l) {
         const cogs_llm_layer& L = h->llm_layers[l];
         const bool fuse_norm = (S == 1);   // single-token decode: RMSNorm runs inside the GEMV prologue
+        const void* xin = (embeds_in_place && l == 0) ? embeds : (const void*)x;    // the residual stream entering this layer
         if (!fuse_norm) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.in_ln, S, H, w.rms_eps)); }
         {
             CogsGemm g; g.dtype = dt;
-            g.A = fuse_norm ? x : ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = qd;
+            g.A = fuse_norm ? xin : ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = qd;
             g.bias = L.qkv_b; g.M = S; g.N = qd; g.K = H;
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = qd_q + kvd; g.head_dim = hd;
             if (prescale_q) { g.q_scale = scale * 1.4426950408889634f; g.q_cols = qd_q; }
@@ -703,7 +707,7 @@ static cogs_status llm_forward_impl(cogs_handle h, cogs_stream stream, const voi
         {
             CogsGemm g; g.dtype = dt;
             g.A = att; g.lda = qd_q; g.W = L.o_w; g.ldw = qd_q; g.C = x; g.ldc = H;
-            g.residual = x; g.ldr = H; g.M = S; g.N = H; g.K = qd_q;
+            g.residual = xin; g.ldr = H; g.M = S; g.N = H; g.K = qd_q;
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         if (!fuse_norm) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_rmsnorm(st, dt, x, ln, L.post_ln, S, H, w.rms_eps)); }

@@ -187,11 +187,11 @@ class Qwen2Engine:
             if do_sample:
                 tok_dev = ops.sample(logits, top_k or 0, 1.0 if top_p is None else top_p,
                                      draws=self._draws(generator) if sampler == "host" else None,
-                                     seed=seed or 0, offset=step, temperature=temperature)
+                                     seed=seed or 0, offset=step, temperature=temperature, out=toks[step:step + 1])
             else:
-                tok_dev = ops.argmax(logits)
-            toks[step:step + 1].copy_(tok_dev)
-            seen[n_seen:n_seen + 1].copy_(tok_dev)
+                tok_dev = ops.argmax(logits, out=toks[step:step + 1])      # straight into the generated-ids buffer
+            if repetition_penalty != 1.0:                                  # the penalty history (nothing else reads it)
+                seen[n_seen:n_seen + 1].copy_(tok_dev)
             n_seen += 1
             produced += 1
             last = step + 1 == max_new_tokens

@@ -213,9 +213,12 @@ def kmeans_update(feats, ts, assign, reseed_rows, centres, centre_ts, ws) -> tor
     return shift
 
 
-def argmax(logits: torch.Tensor) -> torch.Tensor:
-    _need_cuda(logits)
-    out = torch.empty(1, device=logits.device, dtype=torch.int64)
+def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out: an int64 [1] device tensor (e.g. a slot of the generated-ids buffer) to write the index into"""
+    _need_cuda(logits, out)
+    if out is None:
+        out = torch.empty(1, device=logits.device, dtype=torch.int64)
+    assert out.dtype == torch.int64 and out.numel() == 1 and out.is_contiguous()
     ws = torch.empty(128, device=logits.device, dtype=torch.float32)
     check(L.lib.cogs_argmax(current_stream(), ptr(logits), logits.numel(), ptr(out), ptr(ws)), "cogs_argmax")
     return out
