@@ -19,13 +19,14 @@ for name, M, N, K in shapes:
     a = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
     w = ((torch.rand(N, K, device=dev) * 2 - 1) * 0.05).bfloat16()
     bias = torch.rand(N, device=dev).bfloat16()
+    res = torch.rand(M, N, device=dev).bfloat16() if (os.environ.get("AB_RESIDUAL") == "1" and N <= 4608) else None
     outs, ts = {}, {"default": [], "alt": []}
     for r in range(7):
         for tag, lib in (("default", None), ("alt", alt)):
             out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ops.gemm(a, w, bias=bias, out=out, lib=lib)
+            ops.gemm(a, w, bias=bias, residual=res, out=out, lib=lib)
             e1.record()
             torch.cuda.synchronize()
             if r:
