@@ -280,6 +280,30 @@ def test_attention_prescaled_q_causal_gqa(dev, S, pos0):
         assert rel_err(out2.float(), ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("hq,hkv", [(28, 4), (16, 1), (4, 4), (6, 2)])
+@pytest.mark.parametrize("ctx,nsplit", [(1, 2), (63, 2), (64, 3), (65, 2), (255, 4), (256, 4), (257, 5), (1000, 8), (1000, 33),
+                                        (4100, 17)])
+def test_decode_attention_kernel_edges(dev, hq, hkv, ctx, nsplit):
+    """The generated tokens' attention (csrc/attn_decode.hip: one query row, every wave owns whole 64-key tiles, four
+    waves merged in LDS, partials combined by attn_combine_kernel): contexts around every tile boundary, splits with a
+    ragged last tile, with fewer tiles than waves and with no tile at all (nsplit > tiles), 1 / 2 / 7 / 16 query heads
+    per key/value head. Checked per head against the fp32 softmax of the same bf16 inputs."""
+    ops = _ops()
+    hd = 128
+    g = torch.Generator().manual_seed(ctx * 131 + nsplit * 7 + hq)
+    q = (torch.randn(1, hq * hd, generator=g) * (LOG2E / math.sqrt(hd))).bfloat16()
+    k = torch.randn(ctx, hkv * hd, generator=g).bfloat16()
+    v = torch.randn(ctx, hkv * hd, generator=g).bfloat16()
+    if ctx > 4:
+        k[ctx // 2] *= 4.0                       # one dominant key in the middle: the running maximum moves inside a split
+    ref = _attn_ref(q, k, v, hq, hkv, hd, causal=True, q_pos0=ctx - 1, scale=math.log(2.0))
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_pos0=ctx - 1,
+                        nsplit=nsplit, q_prescaled=True).float().cpu()
+    assert torch.isfinite(out).all()
+    err = (out - ref).abs().view(hq, hd).amax(1) / ref.abs().view(hq, hd).amax(1).clamp_min(1e-3)
+    assert float(err.max()) < 2e-2, (float(err.max()), int(err.argmax()))
+
+
 def test_attention_integer_exact(dev):
     """layout check: one-hot attention (huge scale) must copy integer V rows exactly"""
     ops = _ops()
