@@ -104,6 +104,12 @@ __global__ __launch_bounds__(256) void sample_slice_topk_kernel(const float* __r
     }
 }
 
+#ifdef COGS_SAMPLE_STAMPS     // diagnostic build (tools/micro/sample_micro.cpp): s_memtime at the phase boundaries of the merge
+__device__ unsigned long long g_sample_stamps[8];
+#define SSTAMP(i_) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_sample_stamps[i_] = t_; } } while (0)
+#else
+#define SSTAMP(i_) do {} while (0)
+#endif
 // ---- fast path, stage B: merge the candidates, top-p, sample ----
 __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __restrict__ cand_key, const int* __restrict__ cand_idx,
                                                             int k, float lim, const float* __restrict__ draws, uint64_t seed,
@@ -119,6 +125,7 @@ __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __re
     __shared__ uint32_t t0_sh;
     __shared__ int nsurv_sh;
     const int tid = threadIdx.x;
+    SSTAMP(0);
     // prefilter: the slice whose k-th candidate is largest already holds k keys >= that value T0, so the global k-th
     // largest key is >= T0 and every candidate below T0 is out. What is left (k .. a few k) is ranked; ranking all
     // 64 * k candidates against each other was 100+ us of LDS scanning per token.
@@ -126,10 +133,27 @@ __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __re
         uint32_t kth = cand_key[tid * SA_KMAX + k - 1];                 // 0 when the slice has fewer than k candidates
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) kth = max(kth, (uint32_t)__shfl_xor((int)kth, o, 64));
-        if (tid == 0) { t0_sh = kth; nsurv_sh = 0; m_sh = 0; ties_sh = 0; }
+        // a second certified lower bound on the k-th largest key: the k-th largest of the 64 slice maxima (k slices
+        // hold a candidate >= it). On flat rows (and on i.i.d. test data) every slice's k-th candidate is about the same,
+        // T0 alone keeps 700+ of the 1 280 candidates and the rank scan below took 45 + 35 us; the two bounds complement
+        // each other (peaked rows: the top-k sit in few slices, whose k-th candidates are high).
+        uint32_t v0 = 0u;
+        if (k <= SA_BLOCKS) {
+            const uint32_t mine = cand_key[tid * SA_KMAX];
+            int rank = 0;
+            for (int i = 0; i < 64; ++i) {
+                const uint32_t o = (uint32_t)__shfl((int)mine, i, 64);
+                rank += (o > mine || (o == mine && i < tid)) ? 1 : 0;
+            }
+            v0 = rank == k - 1 ? mine : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v0 = max(v0, (uint32_t)__shfl_xor((int)v0, o, 64));
+        }
+        if (tid == 0) { t0_sh = max(kth, v0); nsurv_sh = 0; m_sh = 0; ties_sh = 0; }
     }
     __syncthreads();
     const uint32_t T0 = t0_sh;
+    SSTAMP(1);
     for (int j = tid; j < SA_BLOCKS * k; j += 1024) {
         const int b = j / k, r = j % k;
         const uint32_t key = cand_key[b * SA_KMAX + r];
@@ -140,6 +164,7 @@ __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __re
     }
     __syncthreads();
     const int nsurv = min(nsurv_sh, SA_BLOCKS * SA_KMAX);
+    SSTAMP(2);
     const int nc = (nsurv + 3) & ~3;                                    // padded with "no candidate" entries
     if (tid < nc - nsurv) { ck[nsurv + tid] = 0u; ci[nsurv + tid] = 0x7fffffff; }
     __syncthreads();
@@ -166,6 +191,7 @@ __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __re
     }
     __syncthreads();
     const int m0 = m_sh;   // = min(k, number of candidates)
+    SSTAMP(3);
     if (m0 == k) {         // HF keeps every score >= the k-th largest: ties of the threshold value survive too
         const uint32_t thr = sk[k - 1];
         for (int j = tid; j < nc; j += 1024) {
@@ -179,6 +205,7 @@ __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __re
     }
     __syncthreads();
     const int m = min(m0 + ties_sh, KEPT_MAX);
+    SSTAMP(4);
     if (m == 0) { if (tid == 0) { out_token[0] = 0; if (n_kept) n_kept[0] = 0; } return; }
     // exp and the exponential draw of every kept candidate in parallel (a Philox draw is ~100 instructions: done one
     // after the other by thread 0 they were most of this kernel's 72 us); the sums below keep their sequential order,
@@ -191,6 +218,7 @@ __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __re
     }
     __syncthreads();
     if (tid != 0) return;
+    SSTAMP(5);
     // probabilities of the kept scores (softmax over the row with everything else at -inf), fp32 like torch
     float sum = 0.f;
     for (int j = 0; j < m; ++j) sum += ev[j];
@@ -212,6 +240,7 @@ __global__ __launch_bounds__(1024) void sample_merge_kernel(const uint32_t* __re
         if (sc > best || (sc == best && si[j] < best_i)) { best = sc; best_i = si[j]; }
         if (kept_idx && j < kept_cap) { kept_idx[j] = si[j]; kept_prob[j] = p; }
     }
+    SSTAMP(6);
     out_token[0] = best_i;
     if (n_kept) n_kept[0] = keep;
 }
