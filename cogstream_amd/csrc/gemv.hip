@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
         }
     };
     // Weights are read exactly once per token by exactly one CU: non-temporal loads keep them from displacing what IS
-    // re-read (x, the KV cache, the next kernels' operands) in L2 / the Infinity Cache (A/B: COGS_GEMV_NT=0 at build time)
+    // re-read (x, the KV cache, the next kernels' operands) in L2 / the Infinity Cache (A/B: build with -DCOGS_GEMV_NO_NT)
     auto ldw = [](const T* q) -> u32x4 {
 #ifndef COGS_GEMV_NO_NT
         return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q));
