@@ -10,6 +10,8 @@
 #include "kernels.h"
 #include "gemm_epilogue.h"
 
+// 16-byte chunks per row in flight per lane (R * U = 8 loads); swept with tools/micro/gemv_micro.cpp: (2 rows, U 4) and
+// (4 rows, U 2) are the fastest or level on every decode shape (U 7 / 8 / 3 / 4: within +-4 %, each slower somewhere)
 #ifndef GEMV_U_SMALL
 #define GEMV_U_SMALL 4
 #endif
