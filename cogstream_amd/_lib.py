@@ -11,6 +11,7 @@ import os as _os
 LIB_PATH = Path(_os.environ.get("COGS_LIB_PATH", str(_HERE / "libcogs_hip.so")))  # override: A/B experiments only
 
 DT_BF16, DT_F32 = 0, 1
+OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_WORKSPACE = 0, -1, -2, -3, -4      # cogs_status (include/cogs.h)
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
 ATTN_BLOCK_DIAG, ATTN_REF_EAGER_GLOBAL = 0, 1
 
@@ -50,7 +51,6 @@ class GemmDesc(C.Structure):
         ("rope_maxpos", c_int),
         ("row_stats", c_void_p),
         ("ln_ab", c_void_p),
-        ("col_s", c_void_p),
         ("col_c", c_void_p),
     ]
 
@@ -75,7 +75,7 @@ class AttnDesc(C.Structure):
 class VitLayer(C.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "ln1_g", "ln1_b", "qkv_w", "qkv_b", "o_w", "o_b", "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-        "qkv_s", "qkv_c", "fc1_s", "fc1_c")]
+        "qkv_c", "fc1_c")]
 
 
 class VitWeights(C.Structure):

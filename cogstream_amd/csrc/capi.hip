@@ -123,7 +123,7 @@ CogsGemm to_gemm(const cogs_gemm_desc* d) {
     g.M = d->M; g.N = d->N; g.K = d->K; g.act = d->act; g.out_f32 = d->out_f32;
     g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.rope_cols = d->rope_cols; g.head_dim = d->head_dim;
     g.rope_lut = d->rope_lut; g.rope_rowpos = d->rope_rowpos; g.rope_maxpos = d->rope_maxpos;
-    g.row_stats = d->row_stats; g.ln_ab = d->ln_ab; g.col_s = d->col_s; g.col_c = d->col_c;
+    g.row_stats = d->row_stats; g.ln_ab = d->ln_ab; g.col_c = d->col_c;
     return g;
 }
 
@@ -395,12 +395,12 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
     if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
     char* qkv = (char*)big;
     char* att = qkv + (size_t)N * 3 * H * es;
-    // LayerNorm folded into the GEMMs (bf16 production path, cogs_vit_layer.qkv_s ...): the buffer that would hold LN(x)
+    // LayerNorm folded into the GEMMs (bf16 production path, cogs_vit_layer.qkv_c ...): the buffer that would hold LN(x)
     // carries the per-row partial statistics [N][H/64][2] and the per-row (rstd, -rstd*mean) [N][2] instead
     bool fold = dt == COGS_DT_BF16 && H % 64 == 0;
     for (int l = 0; l < w.layers && fold; ++l) {
         const cogs_vit_layer& L = h->vit_layers[l];
-        fold = L.qkv_s && L.qkv_c && L.fc1_s && L.fc1_c;
+        fold = L.qkv_c && L.fc1_c;
     }
     float* stat_part = (float*)ln;
     float* ln_ab = stat_part + (size_t)N * (H / 64) * 2;
@@ -462,7 +462,7 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
             CogsGemm g; g.dtype = dt;
             g.A = fold ? x : ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = 3 * H;
             g.M = (int)N; g.N = 3 * H; g.K = H;
-            if (fold) { g.ln_ab = ln_ab; g.col_s = L.qkv_s; g.col_c = L.qkv_c; }
+            if (fold) { g.ln_ab = ln_ab; g.col_c = L.qkv_c; }
             else g.bias = L.qkv_b;
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = 2 * H; g.head_dim = hd;
             if (prescale_q) { g.q_scale = scale * 1.4426950408889634f; g.q_cols = H; }
@@ -492,7 +492,7 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
             CogsGemm g; g.dtype = dt;
             g.A = fold ? x : ln; g.lda = H; g.W = L.fc1_w; g.ldw = H; g.C = big; g.ldc = w.inter_pad;
             g.M = (int)N; g.N = w.inter_pad; g.K = H; g.act = COGS_ACT_GELU_TANH;
-            if (fold) { g.ln_ab = ln_ab; g.col_s = L.fc1_s; g.col_c = L.fc1_c; }
+            if (fold) { g.ln_ab = ln_ab; g.col_c = L.fc1_c; }
             else g.bias = L.fc1_b;
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }

@@ -722,6 +722,9 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return COGS_E_INVALID;
     if (g.K % BK != 0 || g.N % 4 != 0) return COGS_E_INVALID;
     if ((g.lda * es) % 16 != 0 || (g.ldw * es) % 16 != 0) return COGS_E_INVALID;
+    // the fused-LayerNorm features exist in the specialised MFMA epilogues only: the single-row GEMV and the run-time
+    // (EPI_GENERIC) epilogue know neither, and silently dropping them would return un-normalised rows
+    if ((g.row_stats || g.ln_ab) && (g.M == 1 || cogs_epi_mask(g) == EPI_GENERIC)) return COGS_E_UNSUPPORTED;
     if (g.M == 1) { ++g_gemm_launches; return cogs_k_gemv(st, g); }
     if (g.rms_gamma) return COGS_E_UNSUPPORTED;   // fused RMSNorm exists for the single-token GEMV only
     GemmArgs p;
@@ -760,36 +763,61 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         // Round-aligned split. The persistent kernel walks nbm*nbn tiles with 256 workgroups; when the last round
         // is mostly empty (N = 1152 at cfg2: 1155 tiles = 4.5 rounds, half the CUs idle for a whole tile time) the
         // leading row blocks that make up WHOLE rounds stay here and the remaining rows go to the 256x128 kernel,
-        // whose half-size tiles fill the chip again (rows are independent: same arithmetic per row).
+        // whose half-size tiles fill the chip again (rows are independent: same arithmetic per row, same K order, so
+        // a row's result does not depend on which kernel computed it).
         static const bool env_nosplit = getenv("COGS_GEMM_NOSPLIT") != nullptr;
         const int nb = p.nbm * p.nbn;
         const int rounds = nb / PERSISTENT_WGS, rem = nb % PERSISTENT_WGS;
-        // (pays when a tile is long against a second launch and the last round is less than ~45 % full: measured
-        // with the two-segment K loop at K = 1152: -2 %; K = 3584, last round 34 % full: +2 %; K = 18944, 34 %: +6 %;
-        // K = 4352, 51 % full (ViT fc2): -2 %, so it no longer splits)
-        if (!env_nosplit && !env_nostore && g.K >= 2048 && rounds >= 2 && rem > 0 && rem * 100 < PERSISTENT_WGS * 45) {
-            const int mb_main = rounds * PERSISTENT_WGS / p.nbn;          // whole row blocks within the full rounds
-            const int rows_main = mb_main * BM3, rows_rem = g.M - rows_main;
-            if (mb_main > 0 && rows_rem >= 512) {
-                CogsGemm b = g;
-                b.M = rows_rem; b.force_mid_tile = 1;
-                b.A = (const char*)g.A + (size_t)rows_main * g.lda * es;
-                b.C = (char*)g.C + (size_t)rows_main * g.ldc * (g.out_f32 ? 4 : es);
-                if (g.residual) b.residual = (const char*)g.residual + (size_t)rows_main * g.ldr * es;
-                if (g.rope_rowpos) b.rope_rowpos = g.rope_rowpos + rows_main;
-                if (g.row_stats) b.row_stats = g.row_stats + (size_t)rows_main * (g.N / 64) * 2;
-                if (g.ln_ab) b.ln_ab = g.ln_ab + (size_t)rows_main * 2;
-                if (g.rope_cos) {
-                    const size_t per_row = (size_t)(g.head_dim / 2) * (g.rope_sin ? 1 : 2);
-                    b.rope_cos = g.rope_cos + (size_t)rows_main * per_row;
-                    if (g.rope_sin) b.rope_sin = g.rope_sin + (size_t)rows_main * per_row;
+        int mb_main = -1;      // >= 0: row blocks that stay in this kernel (0 = none: the whole GEMM goes to the ring kernel)
+        if (!env_nosplit && !env_nostore && nb <= 2 * PERSISTENT_WGS) {
+            // Few tiles (one rank's share of a frame-sharded clip: M = 6 400 is 125 tiles for N = 1152 and 350 = 1.37
+            // rounds for QKV): the time is rounds x one tile, so the choice is by rounds. Calibrated on the four ViT
+            // shapes at M = 3 200 .. 14 784 (tools/cal_tiles.sh, rocprofv3): a round of 256x128 ring tiles takes 0.64-0.68 of a
+            // round of ping-pong tiles of the same K; a second launch costs about 0.08 of one.
+            const int rbm = (g.M + BM2 - 1) / BM2, rbn = (g.N + BN - 1) / BN;
+            auto ring_rounds = [&](int row_blocks) { return (row_blocks * rbn + PERSISTENT_WGS - 1) / PERSISTENT_WGS; };
+            const float c_ring = 0.66f, c_launch = 0.08f;
+            const float cost_pp = (float)((nb + PERSISTENT_WGS - 1) / PERSISTENT_WGS);
+            const float cost_ring = c_ring * ring_rounds(rbm);
+            float best = cost_pp;
+            if (cost_ring < best) { best = cost_ring; mb_main = 0; }
+            if (rounds == 1 && rem > 0) {
+                const int mb = PERSISTENT_WGS / p.nbn;                 // whole row blocks inside the first round
+                const int rows_rem = g.M - mb * BM3;
+                if (mb > 0 && rows_rem >= 256) {
+                    const float cost_split = 1.f + c_ring * ring_rounds((rows_rem + BM2 - 1) / BM2) + c_launch;
+                    if (cost_split < best) { best = cost_split; mb_main = mb; }
                 }
+            }
+        } else if (!env_nosplit && !env_nostore && g.K >= 2048 && rounds >= 2 && rem > 0 && rem * 100 < PERSISTENT_WGS * 45) {
+            // (many tiles: pays when a tile is long against a second launch and the last round is less than ~45 % full:
+            // measured with the two-segment K loop at K = 1152: -2 %; K = 3584, last round 34 % full: +2 %; K = 18944,
+            // 34 %: +6 %; K = 4352, 51 % full (ViT fc2): -2 %, so it no longer splits)
+            const int mb = rounds * PERSISTENT_WGS / p.nbn;          // whole row blocks within the full rounds
+            if (mb > 0 && g.M - mb * BM3 >= 512) mb_main = mb;
+        }
+        if (mb_main >= 0) {
+            const int rows_main = mb_main * BM3;
+            CogsGemm b = g;
+            b.M = g.M - rows_main; b.force_mid_tile = 1;
+            b.A = (const char*)g.A + (size_t)rows_main * g.lda * es;
+            b.C = (char*)g.C + (size_t)rows_main * g.ldc * (g.out_f32 ? 4 : es);
+            if (g.residual) b.residual = (const char*)g.residual + (size_t)rows_main * g.ldr * es;
+            if (g.rope_rowpos) b.rope_rowpos = g.rope_rowpos + rows_main;
+            if (g.row_stats) b.row_stats = g.row_stats + (size_t)rows_main * (g.N / 64) * 2;
+            if (g.ln_ab) b.ln_ab = g.ln_ab + (size_t)rows_main * 2;
+            if (g.rope_cos) {
+                const size_t per_row = (size_t)(g.head_dim / 2) * (g.rope_sin ? 1 : 2);
+                b.rope_cos = g.rope_cos + (size_t)rows_main * per_row;
+                if (g.rope_sin) b.rope_sin = g.rope_sin + (size_t)rows_main * per_row;
+            }
+            if (mb_main > 0) {
                 p.M = rows_main; p.nbm = mb_main;
                 dispatch_pp(st, p, p.nbm * p.nbn, pp_mask);
                 const int rc2 = COGS_LAUNCH_CHECK();
                 if (rc2 != COGS_OK) return rc2;
-                return cogs_k_gemm(st, b);
             }
+            return cogs_k_gemm(st, b);
         }
         dispatch_pp(st, p, nb, env_nostore ? EPI_NOSTORE : pp_mask);
         return COGS_LAUNCH_CHECK();

@@ -37,8 +37,8 @@
 //                subtracted, folded at load time: sum_k x_k W''[n][k] = sum_k (x_k - mean) W'[n][k]) and applies
 //                y[r][n] = rstd_r * acc[r][n] + c_n, c_n = bias_n + sum_k beta_k W[n][k] -- algebraically LN(x) W^T + bias,
 //                with no normalised copy of x ever written or read and no extra arithmetic in the epilogue (the bias add
-//                becomes an fma). What is neglected: rstd * mean * (sum_k of the bf16 ROUNDING of W''), bounded by
-//                ~6e-4 * |mean / std| of the output scale at K = 1152.
+//                becomes an fma). The term rstd * mean * (sum_k of the bf16-ROUNDED W'') is not evaluated: the packer
+//                (weights.fold_layernorm) makes the rounded rows sum to zero as well, so there is nothing to neglect.
 #define EPI_ROWSTAT 1024
 #define EPI_LNFOLD 2048
 
@@ -61,7 +61,6 @@ struct EpiArgs {
     float* stat_part;           // EPI_ROWSTAT: [M][stat_tiles][2] fp32
     int stat_tiles;             //   = N / 64
     const float* ln_ab;         // EPI_LNFOLD: [M][2] fp32 (rstd, -rstd * mean); the epilogues read rstd only (centred W)
-    const float* col_s;         //   unused by the kernels (kept in the descriptor for reference implementations)
     const float* col_c;         //   [N] fp32 (replaces bias)
 };
 
@@ -711,7 +710,7 @@ inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {
     e->q_scale = g.q_scale; e->q_cols = g.q_scale != 1.f ? g.q_cols : 0;
     e->rope_rowpos = g.rope_rowpos; e->rope_lut_lds = 0; e->rope_maxpos = g.rope_maxpos;
     e->stat_part = g.row_stats; e->stat_tiles = g.N / 64;
-    e->ln_ab = g.ln_ab; e->col_s = g.col_s; e->col_c = g.col_c;
+    e->ln_ab = g.ln_ab; e->col_c = g.col_c;
     if (g.row_stats && (g.N % 64 != 0 || g.out_f32 || g.act == COGS_ACT_SWIGLU)) return COGS_E_INVALID;
     if (g.ln_ab && (!g.col_c || g.act == COGS_ACT_SWIGLU || g.N % 4 != 0)) return COGS_E_INVALID;
     return COGS_OK;

@@ -40,9 +40,9 @@ struct CogsGemm {
     // LayerNorm fused around the GEMM (gemm_epilogue.h EPI_ROWSTAT / EPI_LNFOLD; bf16 kernels):
     float* row_stats = nullptr;              // != null: also write per-row partial (sum, sum of squares) of the outputs,
                                              //   [M][N/64][2] fp32 (N % 64 == 0)
-    const float* ln_ab = nullptr;            // != null: y = ln_ab[r][0] * acc + (ln_ab[r][1] * col_s[n] + col_c[n]) instead of
-    const float* col_s = nullptr;            //   acc + bias (W carries gamma; col_c = bias + W.beta); bias must be null
-    const float* col_c = nullptr;
+    const float* ln_ab = nullptr;            // != null: y = ln_ab[r][0] * acc + col_c[n] instead of acc + bias. W = rows of
+    const float* col_c = nullptr;            //   W0*diag(gamma) made ZERO-SUM over k, col_c = bias + W0.beta; bias must be null
+                                             //   (include/cogs.h, cogs_gemm_desc.ln_ab, has the contract)
 };
 int cogs_k_gemm(hipStream_t st, const CogsGemm& g);
 // (a, b) = (rstd, -rstd * mean) per row from the EPI_ROWSTAT partials [rows][tiles][2]: ab [rows][2]

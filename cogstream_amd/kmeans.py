@@ -17,6 +17,8 @@ import torch
 
 from . import ops
 
+last_stats = {"kpp_passes": 0, "iterations": 0}    # of the most recent call (bench.py: bytes moved per stage)
+
 
 def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int, alpha: float = 2,
                              max_iteration: int = 30, tol: float = 1e-4
@@ -53,7 +55,9 @@ def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int
     centre_ts = ts.index_select(0, rows).contiguous()
     assign = None
     zeros = torch.zeros(K, dtype=torch.int32, device=dev)
+    last_stats["kpp_passes"], last_stats["iterations"] = K - 1, 0
     for _ in range(max_iteration):
+        last_stats["iterations"] += 1
         d2 = ops.kmeans_sqdist(x, centres, None, K, ws)
         assign, counts = ops.kmeans_assign(d2, ts, centre_ts, float(alpha))
         empty = (counts.cpu() == 0).nonzero().flatten().tolist()

@@ -139,17 +139,23 @@ class Qwen2Engine:
                  prompt_ids: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
                  sampler: str = "device", seed: Optional[int] = None,
                  cache: Optional[KVCache] = None, ignore_eos: bool = False,
-                 prefix: Optional[PrefixKV] = None) -> List[int]:
+                 prefix: Optional[PrefixKV] = None, prefilled: Optional[dict] = None) -> List[int]:
         """GenerationMixin.generate with inputs_embeds: prefill, then one cogs_llm_forward per token.
         Returns the NEW token ids only. Logits processors run in HF order:
         repetition penalty -> custom (allowed-id mask) -> temperature -> top-k -> top-p.
         `prefix`: reuse the KV rows of the leading embeddings that are unchanged since the previous call.
+        `prefilled`: the result of a forward(embeds, cache) the caller has already run into `cache` (bench.py times the
+        prefill and the token loop separately this way); the prompt is then not prefilled again.
         Sampling (do_sample): cogs_sample on the device, tokens never visit the host. sampler="device": Philox draws
         keyed by `seed` (default: one draw of the CPU generator) and the step; sampler="host": the CPU generator
         (`generator`, default the global one) makes the [vocab] exponential draws of every step exactly as
         torch.multinomial does in the reference's CPU run, so the sampled ids are the reference's."""
         S = embeds.shape[0]
-        if prefix is not None:
+        if prefilled is not None:
+            assert cache is not None and prefix is None and cache.len >= S and "logits" in prefilled
+            pos_start = cache.len
+            res = prefilled
+        elif prefix is not None:
             assert cache is None
             embeds = embeds.contiguous()
             p = prefix.plan(embeds, S + max_new_tokens)
@@ -174,7 +180,9 @@ class Qwen2Engine:
             seen[:n_prompt] = prompt_ids.reshape(-1).to(self.device)
         toks = torch.empty(max_new_tokens, dtype=torch.int64, device=self.device)
         n_seen, produced = n_prompt, 0
-        check_every = 8
+        # host-drawn sampling (parity mode) consumes one [vocab] draw of the CPU generator per step: steps issued past
+        # the EOS would advance that generator beyond where GenerationMixin stops, so the stop test runs every step
+        check_every = 1 if (do_sample and sampler == "host") else 8
         if do_sample and sampler == "device" and seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
         need_proc = repetition_penalty != 1.0 or allowed is not None     # the temperature is applied inside cogs_sample

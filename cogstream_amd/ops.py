@@ -38,7 +38,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          rope_cos: Optional[torch.Tensor] = None, rope_sin: Optional[torch.Tensor] = None, rope_cols: int = 0,
          head_dim: int = 0, rope_lut: Optional[torch.Tensor] = None, rope_rowpos: Optional[torch.Tensor] = None,
          row_stats: Optional[torch.Tensor] = None, ln_ab: Optional[torch.Tensor] = None,
-         col_s: Optional[torch.Tensor] = None, col_c: Optional[torch.Tensor] = None, lib=None) -> torch.Tensor:
+         col_c: Optional[torch.Tensor] = None, lib=None) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)  (see cogs_gemm in include/cogs.h). lib: another build of the library
     (A/B tests only)"""
     _need_cuda(a, w, bias, residual, out)
@@ -60,8 +60,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     d.rope_cos, d.rope_sin, d.rope_cols, d.head_dim = ptr(rope_cos), ptr(rope_sin), rope_cols, head_dim
     d.rope_lut, d.rope_rowpos = ptr(rope_lut), ptr(rope_rowpos)
     d.rope_maxpos = int(rope_lut.shape[0]) if rope_lut is not None else 0
-    _need_cuda(row_stats, ln_ab, col_s, col_c)
-    d.row_stats, d.ln_ab, d.col_s, d.col_c = ptr(row_stats), ptr(ln_ab), ptr(col_s), ptr(col_c)
+    _need_cuda(row_stats, ln_ab, col_c)
+    d.row_stats, d.ln_ab, d.col_c = ptr(row_stats), ptr(ln_ab), ptr(col_c)
     fn = L.lib.cogs_gemm
     if lib is not None:
         fn = lib.cogs_gemm

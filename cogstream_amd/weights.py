@@ -73,16 +73,58 @@ def _pad_rows(x: torch.Tensor, rows: int) -> torch.Tensor:
     return out
 
 
+def zero_sum_rows(wf: torch.Tensor) -> torch.Tensor:
+    """Make every row of a bf16 matrix sum to (essentially) zero by moving a few of its entries ONE bf16 step.
+    A centred row rounded to bf16 keeps a row sum s of about sqrt(K/12) steps; the folded-LayerNorm GEMM never evaluates
+    the term rstd * mean * s (include/cogs.h, cogs_gemm_desc.ln_ab), so s is an error that grows with |mean / std| of an
+    activation row. Greedy, exact in fp64: starting at the row's most populated binade (many candidates, small steps)
+    and going down binade by binade, floor(|s| / step) entries of that binade move one step against the sign of s. What
+    is left is smaller than one step of the row's smallest entries. A moved entry is still a correctly rounded bf16
+    neighbour of its exact value (error < 1.5 steps instead of <= 0.5); about ten of 1152 entries move."""
+    assert wf.dtype == torch.bfloat16 and wf.dim() == 2
+    w = wf.double()
+    mag = w.abs()
+    tiny = 2.0 ** -126
+    expo = torch.floor(torch.log2(mag.clamp_min(tiny)))
+    # log2 of an exact power of two is exact in fp64, but guard the binade edges against a 1-ulp slip of log2
+    expo = torch.where(torch.ldexp(torch.ones_like(mag), expo.int()) > mag, expo - 1, expo)
+    expo = torch.where(torch.ldexp(torch.ones_like(mag), (expo + 1).int()) <= mag, expo + 1, expo)
+    live = mag >= 2.0 ** -100                       # zeros (padding rows / columns) and denormal dust never move
+    s = w.sum(dim=1)
+    if not bool(live.any()):
+        return wf
+    e_hi = int(expo[live].max().item())
+    e_lo = int(expo[live].min().item())
+    # per row: the most populated binade
+    levels = torch.arange(e_lo, e_hi + 1, device=w.device, dtype=torch.float64)
+    counts = torch.stack([((expo == lv) & live).sum(dim=1) for lv in levels.tolist()], dim=1)       # [rows, levels]
+    start = levels[counts.argmax(dim=1)]                                                              # [rows]
+    for lv in reversed(levels.tolist()):
+        step = 2.0 ** (lv - 7)                      # bf16: 8 significant bits
+        cand = (expo == lv) & live & (start >= lv)[:, None]
+        want = torch.floor(s.abs() / step)
+        rank = torch.cumsum(cand.to(torch.int32), dim=1)
+        take = cand & (rank.double() <= want[:, None])
+        delta = -torch.sign(s)[:, None] * step * take.double()
+        w = w + delta
+        s = s + delta.sum(dim=1)
+    out = w.to(torch.bfloat16)
+    assert bool((out.double() == w).all()), "a moved weight is not a bf16 value"
+    return out
+
+
 def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
     """Linear(LayerNorm(x)) with the affine part folded into the linear layer (modeling_videollama3_encoder.py:382-391):
     LN(x) W^T + b = rstd (x - mean) (W diag(gamma))^T + (b + W beta). The rows of W' = W diag(gamma) are CENTRED (their
     mean over the input dimension subtracted; zero-padded input columns excluded): sum_k x_k W''[n][k] then equals
-    sum_k (x_k - mean) W'[n][k] and the GEMM epilogue only evaluates rstd * acc + c (cogs_gemm_desc.ln_ab / col_c).
-    Returns (W'' rounded to W's dtype, s = fp32 row sums of the ROUNDED W'' -- the neglected residue, ~1e-2 |w| at
-    K = 1152 -- and c = fp32 b + W beta)."""
+    sum_k (x_k - mean) W'[n][k] and the GEMM epilogue only evaluates rstd * acc + c (cogs_gemm_desc.ln_ab / col_c). In
+    bf16 the ROUNDED rows are made zero-sum as well (zero_sum_rows), which is what the contract in include/cogs.h asks
+    for. Returns (W'' in W's dtype, s = fp32 row sums of the stored W'' (~0; for tests), c = fp32 b + W beta)."""
     wd = w.double() * gamma.double()[None, :]
     wd = wd - wd.mean(dim=1, keepdim=True)
     wf = wd.to(w.dtype)
+    if wf.dtype == torch.bfloat16:
+        wf = zero_sum_rows(wf)
     s = wf.double().sum(dim=1).float().contiguous()
     c = (b.double() + w.double() @ beta.double()).float().contiguous()
     return wf.contiguous(), s, c
@@ -125,8 +167,8 @@ class PackedVit:
             qkv_w = torch.cat([qw, kw, g(a + "v_proj.weight")], 0)
             qkv_b = hold(torch.cat([qb, kb, g(a + "v_proj.bias")], 0))
             if self.fold_ln:
-                qkv_w, s_, c_ = fold_layernorm(qkv_w, qkv_b, ln1_g, ln1_b)
-                lay.qkv_s, lay.qkv_c = hold(s_).data_ptr(), hold(c_).data_ptr()
+                qkv_w, _, c_ = fold_layernorm(qkv_w, qkv_b, ln1_g, ln1_b)
+                lay.qkv_c = hold(c_).data_ptr()
             lay.qkv_w = hold(qkv_w).data_ptr()
             lay.qkv_b = qkv_b.data_ptr()
             lay.o_w = hold(g(a + "out_proj.weight")).data_ptr()
@@ -136,8 +178,8 @@ class PackedVit:
             fc1_w = _pad_rows(g(p + "mlp.fc1.weight"), self.inter_pad)
             fc1_b = hold(_pad_rows(g(p + "mlp.fc1.bias"), self.inter_pad))
             if self.fold_ln:
-                fc1_w, s_, c_ = fold_layernorm(fc1_w, fc1_b, ln2_g, ln2_b)
-                lay.fc1_s, lay.fc1_c = hold(s_).data_ptr(), hold(c_).data_ptr()
+                fc1_w, _, c_ = fold_layernorm(fc1_w, fc1_b, ln2_g, ln2_b)
+                lay.fc1_c = hold(c_).data_ptr()
             lay.fc1_w = hold(fc1_w).data_ptr()
             lay.fc1_b = fc1_b.data_ptr()
             lay.fc2_w = hold(pad_cols(g(p + "mlp.fc2.weight"), slab)).data_ptr()

@@ -110,12 +110,21 @@ typedef struct {
      * row_stats != NULL: the GEMM also writes, per output row and 64-column block, (sum, sum of squares) of its fp32
      *   results: row_stats [M][N/64][2] fp32 (N % 64 == 0, no SWIGLU / fp32 output); cogs_ln_finalize turns them into
      *   ln_ab [M][2] = (rstd, -rstd * mean).
-     * ln_ab != NULL: the GEMM computes LN(A) . W0^T + bias0 WITHOUT a normalised copy of A: W must hold
-     *   W0 * diag(gamma), col_s [N] = row sums of that W (fp32), col_c [N] = bias0 + W0 . beta (fp32), bias NULL; the
-     *   epilogue evaluates ln_ab[r][0] * acc + (ln_ab[r][1] * col_s[n] + col_c[n]) before rope / activation. */
+     * ln_ab != NULL: the GEMM computes LN(A) . W0^T + bias0 WITHOUT a normalised copy of A. What the kernels evaluate
+     *   is exactly  y[r][n] = ln_ab[r][0] * acc[r][n] + col_c[n]  (before rope / activation; bias must be NULL), where
+     *   acc = A . W^T on the UN-normalised rows of A. That equals LN(A) . W0^T + bias0 if and only if the caller passes
+     *     W [n][k]  = W0[n][k] * gamma[k] - mean_k(W0[n][:] * gamma)      (every row of W sums to ZERO over k: the
+     *                 mean term  -rstd * mean_r * sum_k W[n][k]  of the LayerNorm then vanishes and is NOT evaluated;
+     *                 ln_ab[r][1] is not read), stored in `dtype`;
+     *     col_c [n] = bias0[n] + sum_k W0[n][k] * beta[k]                 (fp32 [N]).
+     *   A W whose rows do not sum to zero gives wrong results without any error. The rounding of W to bf16 leaves a
+     *   row sum s_n != 0, i.e. an error rstd * mean * s_n that grows with |mean / std| of a row of A;
+     *   cogstream_amd.weights.fold_layernorm removes it by moving a handful of weights per row one bf16 step so that
+     *   the ROUNDED row sums to zero too (|s_n| < one step of the row's smallest weights). The four specialised
+     *   epilogues that exist: {LNFOLD, LNFOLD + rope, LNFOLD + GELU_TANH} with M >= 2; anything else (M == 1,
+     *   residual / GELU_ERF / SWIGLU / fp32 output together with ln_ab or row_stats) returns COGS_E_UNSUPPORTED. */
     float* row_stats;
     const float* ln_ab;
-    const float* col_s;
     const float* col_c;
 } cogs_gemm_desc;
 cogs_status cogs_gemm(cogs_stream stream, const cogs_gemm_desc* d);
@@ -232,14 +241,14 @@ cogs_status cogs_sample(cogs_stream stream, const float* logits, int n, float te
  * Packing done once at load (cogstream_amd/weights.py): patch_w [hidden, patch_pad] zero padded;
  * qkv_w [3*hidden, hidden] = q,k,v rows stacked, q/k rows of each head interleaved as rotary pairs;
  * fc1_w [inter_pad, hidden], fc1_b [inter_pad], fc2_w [hidden, inter_pad] zero padded.
- * LayerNorm folding (bf16 production path; all four pointers non-NULL and hidden % 64 == 0): qkv_w / fc1_w then hold
- * W * diag(ln_gamma) (rounded once to bf16), qkv_s / fc1_s [rows] fp32 = the row sums of those folded matrices and
- * qkv_c / fc1_c [rows] fp32 = bias + W . ln_beta; the encoder then never materialises LN(x): the GEMMs that write the
- * residual stream emit per-row statistics and the QKV / fc1 GEMMs apply them in their epilogue (cogs_gemm_desc.ln_ab).
+ * LayerNorm folding (bf16 production path; both pointers non-NULL and hidden % 64 == 0): qkv_w / fc1_w then hold
+ * the rows of W * diag(ln_gamma) with their mean over k removed -- every row sums to zero, see cogs_gemm_desc.ln_ab for
+ * the exact contract -- and qkv_c / fc1_c [rows] fp32 = bias + W . ln_beta; the encoder then never materialises LN(x):
+ * the GEMMs that write the residual stream emit per-row statistics and the QKV / fc1 GEMMs apply them in their epilogue.
  * With the pointers NULL (fp32 parity mode) qkv_w / fc1_w are the plain weights and LayerNorm runs as its own kernel. */
 typedef struct {
     const void *ln1_g, *ln1_b, *qkv_w, *qkv_b, *o_w, *o_b, *ln2_g, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
-    const float *qkv_s, *qkv_c, *fc1_s, *fc1_c;
+    const float *qkv_c, *fc1_c;
 } cogs_vit_layer;
 typedef struct {
     int dtype;

@@ -16,7 +16,7 @@ from cogstream_amd.weights import VisionConfig, random_vit_state  # noqa: E402
 dev = torch.device("cuda:0")
 cfg = VisionConfig()
 enc = VisionEncoder(random_vit_state(cfg, 0, dev, torch.bfloat16), cfg, dtype=torch.bfloat16, device=dev)
-T, gh, gw = 64, 22, 42
+T, gh, gw = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 22, 42)
 per = gh * gw
 pix = (torch.randn(T * per, 588, device=dev) * 0.5).to(torch.bfloat16)
 
@@ -45,14 +45,14 @@ def bench(parts, label):
         run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(10):
         run()
     torch.cuda.synchronize()
-    print(f"{label:34s} {(time.perf_counter() - t0) / 5 * 1e3:7.2f} ms per clip")
+    print(f"{label:34s} {(time.perf_counter() - t0) / 10 * 1e3:7.2f} ms per clip")
     return torch.cat(outs)
 
 
-a = bench([(0, 64)], "one batch of 64 frames")
-b = bench([(0, 32), (32, 64)], "two streams x 32 frames")
-c = bench([(0, 16), (16, 32), (32, 48), (48, 64)], "four streams x 16 frames")
+a = bench([(0, T)], f"one batch of {T} frames")
+b = bench([(0, T // 2), (T // 2, T)], f"two streams x {T // 2} frames")
+c = bench([(i * T // 4, (i + 1) * T // 4) for i in range(4)], f"four streams x {T // 4} frames")
 print("bit-identical:", bool(torch.equal(a, b)), bool(torch.equal(a, c)))
