@@ -50,20 +50,10 @@ def check_epilogue_vmem_counts(obj: Path):
     scratch_* instructions count on vmcnt too); fewer than assumed would let LDS-DMA pieces of the next K-tile be
     read before they land. Returns (unsafe, slack, regions): unsafe = [(kernel EPI, region kind, emitted, assumed)]
     with emitted < assumed, slack = the same tuples with emitted > assumed."""
-    tmp = obj.parent / "epi_check"
-    tmp.mkdir(exist_ok=True)
-    work = tmp / obj.name
-    work.write_bytes(obj.read_bytes())
-    r = subprocess.run([OBJDUMP, "--offloading", str(work)], capture_output=True, text=True)
-    bundles = sorted(tmp.glob(obj.name + ".*gfx950*"))
-    if r.returncode != 0 or not bundles:
-        raise RuntimeError(f"cannot extract the gfx950 code object of {obj.name}: {r.stdout}{r.stderr}")
-    dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(bundles[0])], capture_output=True, text=True)
-    if dis.returncode != 0:
-        raise RuntimeError(dis.stderr)
+    dis_text = _disassemble(obj, "epi_check")
     bad, slack, regions, kern_epi = [], [], 0, None
     state, count = None, 0
-    for line in dis.stdout.splitlines():
+    for line in dis_text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
         if m:
             k = re.search(r"gemm_tn_pp_kernelILi(\d+)E", m.group(1))
@@ -87,9 +77,45 @@ def check_epilogue_vmem_counts(obj: Path):
             count += 1
     if regions == 0:
         raise RuntimeError("no epilogue region markers found in gemm.o (was the marker asm removed?)")
-    for f in tmp.glob("*"):
-        f.unlink()
     return bad, slack, regions
+
+
+def _disassemble(obj: Path, tag: str) -> str:
+    """text disassembly of the gfx950 code object bundled in a hipcc object file"""
+    tmp = obj.parent / tag
+    tmp.mkdir(exist_ok=True)
+    work = tmp / obj.name
+    work.write_bytes(obj.read_bytes())
+    try:
+        r = subprocess.run([OBJDUMP, "--offloading", str(work)], capture_output=True, text=True)
+        bundles = sorted(tmp.glob(obj.name + ".*gfx950*"))
+        if r.returncode != 0 or not bundles:
+            raise RuntimeError(f"cannot extract the gfx950 code object of {obj.name}: {r.stdout}{r.stderr}")
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(bundles[0])], capture_output=True, text=True)
+        if dis.returncode != 0:
+            raise RuntimeError(dis.stderr)
+        return dis.stdout
+    finally:
+        for f in tmp.glob("*"):
+            f.unlink()
+
+
+def check_m0_uses(obj: Path):
+    """csrc/attn_vit.hip issues its LDS-DMA pieces from inline asm that writes M0 (`s_mov_b32 m0, sN` right in front of
+    `global_load_lds_dwordx4`) without naming M0 as clobbered (hipcc warns about the clobber and never keeps a value in
+    M0 across statements). That assumption is checked here instead: inside attn_vit_pipe_kernel every instruction that
+    mentions m0 must be one of those `s_mov_b32 m0, s..` writes -- a compiler-generated read or write of M0 anywhere in
+    the kernel would mean the two could interleave. Returns the offending lines."""
+    bad, inside = [], False
+    for line in _disassemble(obj, "m0_check").splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+        if m:
+            inside = "attn_vit_pipe_kernel" in m.group(1)
+            continue
+        ins = line.split("//")[0].strip()
+        if inside and re.search(r"\bm0\b", ins) and not re.match(r"^s_mov_b32 m0, s\d+$", ins):
+            bad.append(ins)
+    return bad
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -117,14 +143,21 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             for warn in ex.map(cc, jobs):
                 if warn and verbose:
                     print(warn)
-    if any(sj.stem == "gemm" for sj, _ in jobs) and "COGS_EPI_NOPAIR" not in " ".join(FLAGS):
-        gemm_o = OBJ / "gemm.o"
-        bad, slack, regions = check_epilogue_vmem_counts(gemm_o)
-        stamp = OBJ / "gemm.epi_check.txt"
+    strict = os.environ.get("COGS_STRICT_BUILD") == "1"
+    gemm_o, stamp = OBJ / "gemm.o", OBJ / "gemm.epi_check.txt"
+    # keyed on the stamp being older than the object, not on "compiled in this invocation": a gemm.o left by an
+    # interrupted build (or by tools/build_alt.sh) is checked before it is linked
+    if "COGS_EPI_NOPAIR" not in " ".join(FLAGS) and (not stamp.exists() or stamp.stat().st_mtime < gemm_o.stat().st_mtime):
+        try:
+            bad, slack, regions = check_epilogue_vmem_counts(gemm_o)
+        except (OSError, RuntimeError) as e:      # llvm-objdump missing / extraction failed: cannot verify -> safe build
+            if strict:
+                raise
+            bad, slack, regions = [(-1, f"check not possible ({e})", 0, 0)], [], 0
         if bad:
             msg = "; ".join(f"kernel<EPI={k}> {kind} region: {got} vector-memory instructions, the wait assumes {want}"
                             for k, kind, got, want in bad)
-            if os.environ.get("COGS_STRICT_BUILD") == "1":
+            if strict:
                 raise RuntimeError("epilogue vmem-count check failed: " + msg)
             print("WARNING: epilogue vmem-count check failed (" + msg + "); rebuilding gemm.hip with the conservative "
                   "s_waitcnt (-DCOGS_EPI_CONSERVATIVE)", flush=True)
@@ -139,6 +172,20 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                              f"instructions ({len(slack)} with more: {extra or 'none'})\n")
             if verbose:
                 print(stamp.read_text().strip(), flush=True)
+    attn_o, m0_stamp = OBJ / "attn_vit.o", OBJ / "attn_vit.m0_check.txt"
+    if not m0_stamp.exists() or m0_stamp.stat().st_mtime < attn_o.stat().st_mtime:
+        try:
+            m0_bad = check_m0_uses(attn_o)
+        except (OSError, RuntimeError) as e:
+            if strict:
+                raise
+            print(f"WARNING: M0 check of attn_vit.o not possible ({e})", flush=True)
+            m0_bad = None
+        if m0_bad:
+            raise RuntimeError("attn_vit_pipe_kernel: hipcc generated its own uses of M0 beside the inline-asm LDS-DMA "
+                               "(csrc/attn_vit.hip, dma16): " + "; ".join(m0_bad[:6]))
+        if m0_bad is not None:
+            m0_stamp.write_text("ok: every m0 reference inside attn_vit_pipe_kernel is an inline-asm s_mov_b32 m0, sN\n")
     objs = [OBJ / (s.stem + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB)] + [str(o) for o in objs]

@@ -171,6 +171,7 @@ class CogReasoner:
         lacking = sorted(set(want) - set(reader.weight_map))
         if lacking:
             raise RuntimeError(f"{path}: checkpoint lacks {len(lacking)} tensors of the module tree, e.g. {lacking[:4]}")
+        reader.check_shapes(want)
         vit_v, proj_v, llm_v = ck.state_views(reader, cfgs["tie_word_embeddings"])
         enc = VisionEncoder(vit_v, cfgs["vision"], dtype=torch_dtype, device=dev, attn_mode=modes[attn_implementation])
         proj = Projector(proj_v, dtype=torch_dtype, device=dev)

@@ -140,17 +140,34 @@ class Checkpoint:
             raise FileNotFoundError(f"{path}: shard files named by the index are missing: {missing} "
                                     "(the reference repository ships the index only; the weights are git-LFS objects)")
         self.reads: Counter = Counter()
+        self.alias_reads: Counter = Counter()    # reads through an alias (tied lm_head -> embed_tokens): not "twice"
 
     def names(self) -> List[str]:
         return list(self.weight_map)
 
-    def tensor(self, name: str) -> torch.Tensor:
+    def _file(self, name: str):
         fn = self.weight_map[name]          # KeyError = the checkpoint lacks a tensor the module tree needs
         f = self._files.get(fn)
         if f is None:
             f = self._files[fn] = self._open(os.path.join(self.path, fn), framework="pt", device=self.device)
-        self.reads[name] += 1
+        return f
+
+    def tensor(self, name: str, aliased: bool = False) -> torch.Tensor:
+        f = self._file(name)
+        (self.alias_reads if aliased else self.reads)[name] += 1
         return f.get_tensor(name)
+
+    def shape(self, name: str) -> Tuple[int, ...]:
+        """shape from the shard's header (no tensor data is read)"""
+        return tuple(self._file(name).get_slice(name).get_shape())
+
+    def check_shapes(self, expected: Dict[str, Tuple[int, ...]]) -> None:
+        """every tensor of the module tree has the shape config.json implies -- a shard of another model size fails
+        here, by name, instead of somewhere inside the packers or the kernels"""
+        bad = [(n, self.shape(n), tuple(s)) for n, s in expected.items() if n in self.weight_map and self.shape(n) != tuple(s)]
+        if bad:
+            raise RuntimeError(f"{self.path}: {len(bad)} tensors do not have the shape config.json implies, e.g. "
+                               + "; ".join(f"{n}: {got} != {want}" for n, got, want in bad[:4]))
 
     def close(self):
         self._files.clear()
@@ -179,7 +196,7 @@ class StateView(Mapping):
         return k if k in self.top_level else self.prefix + k
 
     def __getitem__(self, k: str) -> torch.Tensor:
-        return self.ckpt.tensor(self._full(k))
+        return self.ckpt.tensor(self._full(k), aliased=k in self.alias)
 
     def __contains__(self, k) -> bool:
         return self._full(k) in self.ckpt.weight_map
@@ -257,6 +274,9 @@ def save_checkpoint(path: str, vit_state, proj_state, llm_state, vision: VisionC
     with open(os.path.join(path, INDEX), "w") as f:
         json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f)
     cfg = {"architectures": ["Videollama3Qwen2ForCausalLM"], "model_type": "videollama3_qwen2",
+           # the reference's trust_remote_code entry points (model/config.json:6-9); cogstream_amd.auto resolves them
+           "auto_map": {"AutoConfig": "configuration_videollama3.Videollama3Qwen2Config",
+                        "AutoModelForCausalLM": "cogreasoner_chat.Videollama3Qwen2ForCausalLM"},
            "hidden_size": llm.hidden_size, "intermediate_size": llm.intermediate_size,
            "num_hidden_layers": llm.num_hidden_layers, "num_attention_heads": llm.num_attention_heads,
            "num_key_value_heads": llm.num_key_value_heads, "vocab_size": llm.vocab_size, "rms_norm_eps": llm.rms_norm_eps,
@@ -272,3 +292,8 @@ def save_checkpoint(path: str, vit_state, proj_state, llm_state, vision: VisionC
     if generation is not None:
         with open(os.path.join(path, "generation_config.json"), "w") as f:
             json.dump(generation, f, indent=1)
+    with open(os.path.join(path, "preprocessor_config.json"), "w") as f:     # model/preprocessor_config.json:2-5,10-26
+        json.dump({"auto_map": {"AutoImageProcessor": "image_processing_videollama3.Videollama3ImageProcessor",
+                                "AutoProcessor": "processing_cogreasoner.Videollama3Qwen2Processor"},
+                   "image_mean": [0.5, 0.5, 0.5], "image_std": [0.5, 0.5, 0.5], "max_tokens": 16384, "min_tokens": 16,
+                   "patch_size": 14, "resample": 3, "rescale_factor": 1 / 255}, f, indent=1)

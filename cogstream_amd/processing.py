@@ -277,15 +277,17 @@ class CogStreamProcessor:
         self.device, self.pixel_dtype = device, pixel_dtype
 
     @classmethod
-    def from_pretrained(cls, path: str, device=None, pixel_dtype=None, trust_remote_code: bool = True, **unused):
+    def from_pretrained(cls, path: str, device=None, pixel_dtype=None, trust_remote_code: bool = True, tokenizer=None,
+                        **unused):
         """AutoProcessor.from_pretrained(model_path, trust_remote_code=True) (evaluate/answer_generate.py:179): the
-        checkpoint's tokenizer + preprocessor_config.json / processor_config.json settings"""
+        checkpoint's tokenizer + preprocessor_config.json / processor_config.json settings. `tokenizer`: use this
+        object instead of loading vocab.json / merges.txt from the directory (tests: the replayed real tokenizer)"""
         from . import checkpoint as ck
         p = ck.load_configs(path)["processor"]
         if (p["patch_size"], p["resample"], list(p["image_mean"]), list(p["image_std"])) != (14, 3, [0.5] * 3, [0.5] * 3):
             raise ValueError(f"{path}: pre-processing settings other than the reference's (patch 14, bicubic, "
                              "mean/std 0.5) are not implemented")
-        return cls(ck.load_tokenizer(path), video_merge_size=p["video_merge_size"], max_tokens=p["max_tokens"],
+        return cls(tokenizer if tokenizer is not None else ck.load_tokenizer(path), video_merge_size=p["video_merge_size"], max_tokens=p["max_tokens"],
                    min_tokens=p["min_tokens"], device=device, pixel_dtype=pixel_dtype)
 
     def __call__(self, conversation: List[Dict[str, Any]], add_system_prompt: bool = True,

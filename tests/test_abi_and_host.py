@@ -146,3 +146,36 @@ def test_cfg4_history_fixture_and_retrieval_prompt():
     for i, t in enumerate(turns[:-1]):
         assert t["question"] in prompt and t["answer"] in prompt
     assert turns[-1]["question"] in prompt
+
+
+def test_reference_plugin_names_resolve_through_auto_map(tmp_path):
+    """The reference's only extension API is HF auto_map: model/config.json:6-9 names
+    cogreasoner_chat.Videollama3Qwen2ForCausalLM, model/preprocessor_config.json:2-5 names
+    processing_cogreasoner.Videollama3Qwen2Processor (used by evaluate/answer_generate.py:173-183). Both names exist in
+    this package as modules + classes, and cogstream_amd.auto resolves a checkpoint directory's auto_map to them --
+    checked on the reference's own JSON files where they exist, and on a directory written by save_checkpoint."""
+    import json
+    from cogstream_amd import auto
+    from cogstream_amd.cogreasoner_chat import Videollama3Qwen2ForCausalLM
+    from cogstream_amd.processing_cogreasoner import Videollama3Qwen2Processor
+    from cogstream_amd.chat import CogReasoner
+    from cogstream_amd.processing import CogStreamProcessor
+    assert issubclass(Videollama3Qwen2ForCausalLM, CogReasoner) and issubclass(Videollama3Qwen2Processor, CogStreamProcessor)
+    for name in ("qa_selection", "generate", "set_adapter", "load_adapter", "to", "eval", "from_pretrained"):
+        assert callable(getattr(Videollama3Qwen2ForCausalLM, name))
+    for name in ("__call__", "batch_decode", "from_pretrained"):
+        assert callable(getattr(Videollama3Qwen2Processor, name))
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    json.dump({"auto_map": {"AutoModelForCausalLM": "cogreasoner_chat.Videollama3Qwen2ForCausalLM"}}, open(d / "config.json", "w"))
+    json.dump({"auto_map": {"AutoProcessor": "processing_cogreasoner.Videollama3Qwen2Processor"}},
+              open(d / "preprocessor_config.json", "w"))
+    assert auto._resolve(str(d), "config.json", "AutoModelForCausalLM", "x.y") is Videollama3Qwen2ForCausalLM
+    assert auto._resolve(str(d), "preprocessor_config.json", "AutoProcessor", "x.y") is Videollama3Qwen2Processor
+    json.dump({"auto_map": {"AutoModelForCausalLM": "modeling_other.SomethingElse"}}, open(d / "config.json", "w"))
+    with pytest.raises(ValueError):
+        auto._resolve(str(d), "config.json", "AutoModelForCausalLM", "x.y")
+    ref = "/root/reference/model"
+    if os.path.isdir(ref):      # build container only: the reference's own files name exactly these classes
+        assert auto._resolve(ref, "config.json", "AutoModelForCausalLM", "x.y") is Videollama3Qwen2ForCausalLM
+        assert auto._resolve(ref, "preprocessor_config.json", "AutoProcessor", "x.y") is Videollama3Qwen2Processor

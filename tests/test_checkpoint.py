@@ -138,6 +138,55 @@ def test_save_checkpoint_round_trip_and_adapter_dir(tmp_path):
     assert alpha == 8.0 and set(st) == set(lora)
 
 
+def test_tied_embeddings_load_and_wrong_shapes_fail_by_name(tmp_path):
+    """tie_word_embeddings: lm_head.weight is an alias of model.embed_tokens.weight -- PackedLlm reads both names, which
+    is one genuine read plus one aliased read, not 'read more than once'. A shard whose tensor shapes do not match
+    config.json fails in check_shapes with the tensor's name, before any packing."""
+    from safetensors.torch import save_file
+    from cogstream_amd import checkpoint as ck
+    from cogstream_amd.weights import LlmConfig, PackedLlm, VisionConfig, random_llm_state, random_proj_state, random_vit_state
+    vc = VisionConfig(hidden_size=64, intermediate_size=72, num_hidden_layers=1, num_attention_heads=2)
+    lc = LlmConfig(hidden_size=128, intermediate_size=192, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                   vocab_size=320, image_token_index=300, eos_token_id=299)
+    ls = random_llm_state(lc)
+    d = str(tmp_path / "tied")
+    ck.save_checkpoint(d, random_vit_state(vc), random_proj_state(64, 128), ls, vc, lc, n_shards=1)
+    # make it a tied checkpoint: drop lm_head.weight from the shard and the index, flag it in config.json
+    fn = os.path.join(d, "model-00001-of-00001.safetensors")
+    from safetensors import safe_open
+    with safe_open(fn, framework="pt") as f:
+        ts = {k: f.get_tensor(k) for k in f.keys() if k != "lm_head.weight"}
+    save_file(ts, fn)
+    idx = json.load(open(os.path.join(d, ck.INDEX)))
+    del idx["weight_map"]["lm_head.weight"]
+    json.dump(idx, open(os.path.join(d, ck.INDEX), "w"))
+    cfg = json.load(open(os.path.join(d, "config.json")))
+    cfg["tie_word_embeddings"] = True
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    c = ck.load_configs(d)
+    assert c["tie_word_embeddings"] is True
+    r = ck.Checkpoint(d)
+    want = ck.expected_tensors(c["vision"], c["llm"], True)
+    assert "lm_head.weight" not in want and set(want) == set(r.names())
+    r.check_shapes(want)
+    _, _, llm_v = ck.state_views(r, True)
+    packed = PackedLlm(llm_v, lc, torch.bfloat16, "cpu")
+    assert torch.equal(packed.lm_head, packed.embed)                 # the same values, read through the alias
+    assert r.reads["model.embed_tokens.weight"] == 1 and r.alias_reads["model.embed_tokens.weight"] == 1
+    for n in r.names():                                               # the other two sub-trees, then nothing may be left
+        if n.startswith(ck.VIT_PREFIX) or n.startswith(ck.PROJ_PREFIX):
+            r.tensor(n)
+    r.check_consumed()
+    # wrong-size shard: config.json says hidden 128, the tensors say 64
+    lc_bad = LlmConfig(hidden_size=64, intermediate_size=192, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                       vocab_size=320, image_token_index=300, eos_token_id=299)
+    d2 = str(tmp_path / "bad")
+    ck.save_checkpoint(d2, random_vit_state(vc), random_proj_state(64, 64), random_llm_state(lc_bad), vc, lc, n_shards=1)
+    r2 = ck.Checkpoint(d2)
+    with pytest.raises(RuntimeError, match="embed_tokens|readout|layers"):
+        r2.check_shapes(ck.expected_tensors(vc, lc))
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/model"), reason="build container only")
 def test_processor_from_pretrained_on_the_reference_directory():
     """AutoProcessor.from_pretrained equivalent on the reference's own model directory (tokenizer + processor configs

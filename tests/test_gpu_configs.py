@@ -279,3 +279,89 @@ def test_bench_cfg3_mode_and_extra_key(dev):
     assert d["config"]["frames"] == 64 and d["scaling"] == "weak" and d["cfg3"]["frames_per_gpu"] == 256
     assert "140x280" in d["cfg3"]["workload"] and d["cfg3"]["value"] > 0
     assert d["roofline"]["traffic_source"] is None or "not this run" in d["roofline"]["traffic_source"]
+
+
+def test_reference_driver_call_sequence_under_the_reference_names(dev, tmp_path):
+    """evaluate/answer_generate.py:173-183 (load) and :60-76 (infer), statement for statement, with ONE import changed:
+    AutoModelForCausalLM / AutoProcessor / PeftModel come from cogstream_amd.auto, which resolves the checkpoint
+    directory's auto_map (model/config.json:6-9, model/preprocessor_config.json:2-5) to
+    cogstream_amd.cogreasoner_chat.Videollama3Qwen2ForCausalLM / processing_cogreasoner.Videollama3Qwen2Processor.
+    The checkpoint is synthesised (real vocabulary size, small widths), the tokenizer is the REAL one replayed
+    (BASELINE configs[0] conversation: 621 prompt ids), both adapters are peft directories."""
+    from safetensors.torch import save_file
+    from replay_tokenizer import ReplayTokenizer
+    from cogstream_amd import checkpoint as ck
+    from cogstream_amd import processing as pr
+    from cogstream_amd.auto import AutoModelForCausalLM, AutoProcessor, PeftModel        # <- the one changed import
+    from cogstream_amd.cogreasoner_chat import Videollama3Qwen2ForCausalLM
+    from cogstream_amd.processing_cogreasoner import Videollama3Qwen2Processor
+    from cogstream_amd.weights import (LlmConfig, VisionConfig, random_llm_state, random_lora_state, random_proj_state,
+                                       random_vit_state)
+
+    class Tok(ReplayTokenizer):
+        def decode(self, ids, skip_special_tokens=False):          # generated ids are random: no recorded text for them
+            ids = ids.tolist() if hasattr(ids, "tolist") else list(ids)
+            return self.by_ids.get(tuple(ids), " ".join(str(i) for i in ids))
+
+    vcfg = VisionConfig(hidden_size=576, intermediate_size=200, num_hidden_layers=2, num_attention_heads=8)
+    lcfg = LlmConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1)
+    model_path = str(tmp_path / "ckpt")
+    ck.save_checkpoint(model_path, random_vit_state(vcfg, seed=3, std=0.05),
+                       random_proj_state(vcfg.hidden_size, lcfg.hidden_size, seed=1, std=0.05),
+                       random_llm_state(lcfg, seed=7, std=0.05), vcfg, lcfg,
+                       generation={"do_sample": False, "eos_token_id": [151645, 151643]}, n_shards=2)
+    adapters = []
+    for i, name in enumerate(("full", "language")):
+        ad = str(tmp_path / f"adapter_{name}")
+        os.makedirs(ad)
+        lora = random_lora_state(lcfg, seed=20 + i, r=8, proj_dims=(vcfg.hidden_size, lcfg.hidden_size))
+        save_file({k: v.contiguous() for k, v in lora.items()}, os.path.join(ad, "adapter_model.safetensors"))
+        json.dump({"r": 8, "lora_alpha": 16}, open(os.path.join(ad, "adapter_config.json"), "w"))
+        adapters.append(ad)
+    local_rank = dev.index or 0
+    torch.cuda.set_device(local_rank)
+
+    # ---- evaluate/answer_generate.py:173-183
+    model = AutoModelForCausalLM.from_pretrained(
+        model_path,
+        trust_remote_code=True,
+        torch_dtype=torch.bfloat16,
+        attn_implementation="flash_attention_2",
+    )
+    processor = AutoProcessor.from_pretrained(model_path, trust_remote_code=True, tokenizer=Tok())
+    tokenizer = processor.tokenizer
+    model = PeftModel.from_pretrained(model, adapters[0], adapter_name="full_module")
+    model.load_adapter(adapters[1], adapter_name="language_module")
+    model.to(local_rank)
+    assert type(model) is Videollama3Qwen2ForCausalLM and type(processor) is Videollama3Qwen2Processor
+    assert tokenizer is processor.tokenizer and model.active_adapter == "full_module"
+
+    # ---- evaluate/answer_generate.py:60-76 (infer), on the BASELINE configs[0] conversation
+    frames, ts = pr.synthetic_clip(8, 224, 224)
+    conversation = [{"role": "user", "content": [{"type": "video", "video": frames, "timestamps": ts},
+                                                 {"type": "text", "text": "What is happening in the video?"}]}]
+    select, if_visual = None, None
+    inputs = processor(
+        conversation=conversation,
+        add_system_prompt=True,
+        add_generation_prompt=True,
+        return_tensors="pt"
+    )
+    assert inputs["input_ids"].shape == (1, 621)
+    inputs = {k: v.to(model.device) if isinstance(v, torch.Tensor) else v for k, v in inputs.items()}
+    if "pixel_values" in inputs:
+        inputs["pixel_values"] = inputs["pixel_values"].to(dtype=torch.bfloat16)
+    model.set_adapter("language_module")
+    inputs = model.qa_selection(**inputs, mode="FCC", select_gt=select, if_visual=if_visual)
+    model.set_adapter("full_module")
+    output_ids, selection_module_output = model.generate(**inputs, max_new_tokens=6)
+    response = processor.batch_decode(output_ids, skip_special_tokens=True)[0].strip()
+    assert isinstance(response, str) and selection_module_output == "" and output_ids.shape[0] == 1
+    assert 1 <= output_ids.shape[1] <= 6
+    # the adapters are live: the answer stage under the other adapter / the base weights decodes differently
+    lg = {}
+    emb = model.llm.embed_tokens(torch.arange(100, 164, device=dev))
+    for name in ("full_module", "language_module", "base"):
+        model.set_adapter(name)
+        lg[name] = model.llm.forward(emb)["logits"].clone()
+    assert rel_err(lg["full_module"], lg["base"]) > 1e-3 and rel_err(lg["language_module"], lg["full_module"]) > 1e-3
