@@ -138,6 +138,11 @@ SIGNATURES = {
     "cogs_kmeans_assign": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "cogs_kmeans_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "cogs_kmeans_pp_step": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_size_t]),
+    "cogs_kmeans_lloyd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_int, c_float,
+                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, C.POINTER(c_int), C.POINTER(c_int),
+                                  C.POINTER(c_int), c_void_p, c_size_t]),
     "cogs_pack_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int]),
     "cogs_preprocess_workspace_bytes": (c_int, [c_int, c_int, c_int, C.POINTER(c_size_t)]),
     "cogs_preprocess_frames": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

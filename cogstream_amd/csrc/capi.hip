@@ -37,6 +37,9 @@ struct cogs_ctx {
     hipEvent_t stage_ev[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     bool stage_busy[STAGE_SLOTS] = {false, false, false, false};
     int stage_next = 0;
+    // second stream of the frame-split encode (cogs_vit_encode): two halves of a small clip run side by side
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // optional per-kernel-class event profiling (bench/roofline only)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;      // pairs
@@ -185,6 +188,9 @@ cogs_status cogs_destroy(cogs_handle h) {
     }
     if (h->vit_inv_freq) (void)hipFree(h->vit_inv_freq);
     if (h->llm_inv_freq) (void)hipFree(h->llm_inv_freq);
+    if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
     return COGS_OK;
 }
@@ -275,6 +281,25 @@ cogs_status cogs_kmeans_update(cogs_stream stream, int dtype, const void* feats,
     if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
     return cogs_k_kmeans_update((hipStream_t)stream, dtype, feats, ts, T, PD, K, assign, reseed_rows, centres,
                                 centre_ts, (float*)ws, cogs_k_kmeans_update_blocks(PD), shift_out);
+}
+cogs_status cogs_kmeans_pp_step(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD, int row, int first,
+                                float* nearest2, float* probs_host, void* ws, size_t ws_bytes) {
+    int ns = 0;
+    const size_t need = cogs_k_kmeans_ws(T, PD, 1, &ns);
+    if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
+    if (!feats || !nearest2 || T <= 0) return COGS_E_INVALID;
+    return cogs_k_kmeans_pp_step((hipStream_t)stream, dtype, feats, T, PD, row, first, nearest2, probs_host, (float*)ws, ns);
+}
+cogs_status cogs_kmeans_lloyd(cogs_stream stream, int dtype, const void* feats, const float* ts, int T, int64_t PD, int K,
+                              float alpha, int max_iter, float tol, const int32_t* reseed_pool, int pool_len,
+                              float* centres, float* centre_ts, int64_t* assign, int* iterations, int* reseeds_used,
+                              int* pool_exhausted, void* ws, size_t ws_bytes) {
+    int ns = 0;
+    const size_t need = cogs_k_kmeans_ws(T, PD, K, &ns);
+    if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
+    if (!feats || !ts || !centres || !centre_ts || !assign || (pool_len > 0 && !reseed_pool)) return COGS_E_INVALID;
+    return cogs_k_kmeans_lloyd((hipStream_t)stream, dtype, feats, ts, T, PD, K, alpha, max_iter, tol, reseed_pool, pool_len,
+                               centres, centre_ts, assign, iterations, reseeds_used, pool_exhausted, (float*)ws, ns);
 }
 cogs_status cogs_pack_rows(cogs_stream stream, int in_dtype, int out_dtype, const void* in, int64_t ld_in, void* out,
                            int64_t ld_out, int rows, int cols_in, int cols_out) {
@@ -368,16 +393,89 @@ cogs_status cogs_vit_workspace_bytes(cogs_handle h, int64_t n_patches, size_t* b
     Carver c(nullptr, 0);
     void *a, *b, *d, *e; float *rc, *rs; int32_t *cu, *lo, *hi;
     // frames <= patches; size the cu_seqlens array for the worst case
-    *bytes = vit_carve(h->vit, n_patches, (int)n_patches, c, &a, &b, &d, &e, &rc, &rs, &cu, &lo, &hi);
+    // + room for the second set of fixed-size tables when a small clip is encoded as two halves (cogs_vit_encode)
+    *bytes = vit_carve(h->vit, n_patches, (int)n_patches, c, &a, &b, &d, &e, &rc, &rs, &cu, &lo, &hi) + 64 * 1024;
     return COGS_OK;
 }
+
+static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* pixel_values, int pix_dtype,
+                                    const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
+                                    void* out_tokens, void* ws, size_t ws_bytes);
+
+// Frames are independent under block-diagonal attention (per-frame attention, RoPE and 2x2 merge:
+// modeling_videollama3_encoder.py:309-312,427,487-501). A SMALL clip -- one rank's share of a frame-sharded clip -- has
+// too few GEMM tiles per launch to fill 256 CUs (8 frames of 22 x 42 patches: 145 tiles for the N = 1152 shapes), so it
+// is encoded as two halves on two streams: the second half's kernels take the CUs the first half's ragged rounds leave
+// idle. Same arithmetic per row, bit-identical tokens (tests/test_gpu_models.py). Not while the per-kernel profiler is
+// on (overlapping launches stretch every bracket) and not for large clips, whose launches fill the chip on their own.
+static const int64_t VIT_SPLIT_MAX_PATCHES = 32768;
 
 cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
                             const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
                             void* out_tokens, void* ws, size_t ws_bytes) {
     if (!h || !h->vit_ok || !pixel_values || !grid_sizes || !merge_sizes || V <= 0 || !out_tokens) return COGS_E_INVALID;
-    const cogs_vit_weights& w = h->vit;
     hipStream_t st = (hipStream_t)stream;
+    int64_t N = 0, nframes = 0;
+    for (int v = 0; v < V; ++v) {
+        const int64_t t = grid_sizes[3 * v], gh = grid_sizes[3 * v + 1], gw = grid_sizes[3 * v + 2], ms = merge_sizes[v];
+        if (t <= 0 || gh <= 0 || gw <= 0 || ms <= 0 || gh % ms || gw % ms) return COGS_E_INVALID;
+        N += t * gh * gw;
+        nframes += t;
+    }
+    static const bool env_single = getenv("COGS_VIT_STREAMS") && atoi(getenv("COGS_VIT_STREAMS")) == 1;
+    if (!env_single && !h->prof_on && attn_mode == COGS_ATTN_BLOCK_DIAG && nframes >= 2 && N <= VIT_SPLIT_MAX_PATCHES) {
+        // cut at the frame boundary nearest to half the patches
+        std::vector<int64_t> ga, gb, ma, mb;
+        int64_t rows_a = 0, toks_a = 0, fa = 0, best_gap = N + 1, acc = 0;
+        int cut_v = 0; int64_t cut_t = 0;
+        for (int v = 0; v < V; ++v) {
+            const int64_t per = grid_sizes[3 * v + 1] * grid_sizes[3 * v + 2];
+            for (int64_t f = 0; f <= grid_sizes[3 * v]; ++f) {
+                const int64_t r = acc + f * per;
+                const int64_t gap = r > N - r ? 2 * r - N : N - 2 * r;
+                if (r > 0 && r < N && gap < best_gap) { best_gap = gap; cut_v = v; cut_t = f; }
+            }
+            acc += grid_sizes[3 * v] * per;
+        }
+        for (int v = 0; v < V; ++v) {
+            const int64_t t = grid_sizes[3 * v], gh = grid_sizes[3 * v + 1], gw = grid_sizes[3 * v + 2], ms = merge_sizes[v];
+            const int64_t ta = v < cut_v ? t : (v == cut_v ? cut_t : 0), tb = t - ta;
+            if (ta > 0) { ga.insert(ga.end(), {ta, gh, gw}); ma.push_back(ms); rows_a += ta * gh * gw; toks_a += ta * gh * gw / (ms * ms); fa += ta; }
+            if (tb > 0) { gb.insert(gb.end(), {tb, gh, gw}); mb.push_back(ms); }
+        }
+        const cogs_vit_weights& w = h->vit;
+        Carver ca(nullptr, 0), cb(nullptr, 0);
+        void *p0, *p1, *p2, *p3; float *q0, *q1; int32_t *i0, *i1, *i2;
+        const size_t need_a = vit_carve(w, rows_a, (int)fa, ca, &p0, &p1, &p2, &p3, &q0, &q1, &i0, &i1, &i2);
+        const size_t need_b = vit_carve(w, N - rows_a, (int)(nframes - fa), cb, &p0, &p1, &p2, &p3, &q0, &q1, &i0, &i1, &i2);
+        bool ok = ws && need_a + need_b <= ws_bytes && !ma.empty() && !mb.empty();
+        if (ok && !h->aux_stream) {
+            ok = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
+            if (!ok) h->aux_stream = nullptr;
+        }
+        if (ok) {
+            const size_t pes = pix_dtype == COGS_DT_BF16 ? 2 : 4;
+            if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0) != hipSuccess) return COGS_E_HIP;
+            const cogs_status ra = vit_encode_range(h, st, pixel_values, pix_dtype, ga.data(), ma.data(), (int)ma.size(), attn_mode,
+                                                    out_tokens, ws, need_a);
+            const cogs_status rb = vit_encode_range(h, h->aux_stream, (const char*)pixel_values + (size_t)rows_a * w.patch_dim * pes,
+                                                    pix_dtype, gb.data(), mb.data(), (int)mb.size(), attn_mode,
+                                                    (char*)out_tokens + (size_t)toks_a * w.hidden * esize(w.dtype),
+                                                    (char*)ws + need_a, need_b);
+            // join unconditionally: the caller's stream must not run ahead of anything queued on the second one
+            if (hipEventRecord(h->ev_join, h->aux_stream) != hipSuccess || hipStreamWaitEvent(st, h->ev_join, 0) != hipSuccess) return COGS_E_HIP;
+            return ra != COGS_OK ? ra : rb;
+        }
+    }
+    return vit_encode_range(h, st, pixel_values, pix_dtype, grid_sizes, merge_sizes, V, attn_mode, out_tokens, ws, ws_bytes);
+}
+
+static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* pixel_values, int pix_dtype,
+                                    const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
+                                    void* out_tokens, void* ws, size_t ws_bytes) {
+    const cogs_vit_weights& w = h->vit;
     const int dt = w.dtype;
     const size_t es = esize(dt);
     const int H = w.hidden, hd = H / w.heads;

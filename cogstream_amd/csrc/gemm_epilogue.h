@@ -31,7 +31,8 @@
 #define EPI_NOSTORE 256   // diagnostics only (COGS_GEMM_NOSTORE): accumulators kept live, nothing written
 // LayerNorm fused around the GEMMs (model/modeling_videollama3_encoder.py:382-391: x += attn(LN1(x)); x += mlp(LN2(x))):
 //   EPI_ROWSTAT  the GEMM that PRODUCES the residual stream x (patch embed, out-proj, fc2; N = hidden) also writes, per
-//                row and 64-column wave tile, the partial sums (sum x, sum x^2) of its fp32 outputs: stat_part[M][N/64][2].
+//                row and 64-column wave tile, the partial sums (sum x, sum x^2) of the values it STORES (the bf16-rounded
+//                ones in bf16 mode: what the consumer will read): stat_part[M][N/64][2].
 //                A tiny kernel turns them into (a, b) = (rstd, -rstd * mean) per row (cogs_k_ln_finalize).
 //   EPI_LNFOLD   the GEMM that CONSUMES LN(x) reads x itself with W'' = rows of W * diag(gamma) CENTRED (their mean over k
 //                subtracted, folded at load time: sum_k x_k W''[n][k] = sum_k (x_k - mean) W'[n][k]) and applies
@@ -273,22 +274,26 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
                                 va += f32x4{bf_lo(x0[0]), bf_hi(x0[0]), bf_lo(x1[0]), bf_hi(x1[0])};
                                 vb += f32x4{bf_lo(x0[1]), bf_hi(x0[1]), bf_lo(x1[1]), bf_hi(x1[1])};
                             }
+                            const unsigned a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]);
+                            const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
                             if constexpr ((EPI & EPI_ROWSTAT) != 0) {
-                                // the SAME association as epilogue_pair_fast (a 32-column unit summed from zero, units added
+                                // statistics of the STORED (bf16-rounded) values: they are what the consuming GEMM multiplies,
+                                // and on rows dominated by their mean the rounding noise is a visible part of the variance.
+                                // The SAME association as epilogue_pair_fast (a 32-column unit summed from zero, units added
                                 // in order): a row's statistics must not depend on which epilogue its tile happened to take,
                                 // or a frame-sharded encode would differ from the whole-clip encode in the last bit
                                 if (nb + 32 * pr < N) {
+                                    const f32x4 ra = {bf_lo(a0), bf_hi(a0), bf_lo(a1), bf_hi(a1)};
+                                    const f32x4 rb = {bf_lo(b0), bf_hi(b0), bf_lo(b1), bf_hi(b1)};
                                     float u1 = 0.f, u2 = 0.f;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
-                                        u1 += va[e] + vb[e];
-                                        u2 = fmaf(va[e], va[e], fmaf(vb[e], vb[e], u2));
+                                        u1 += ra[e] + rb[e];
+                                        u2 = fmaf(ra[e], ra[e], fmaf(rb[e], rb[e], u2));
                                     }
                                     if (pr == 0) { st1 = u1; st2 = u2; } else { st1 += u1; st2 += u2; }
                                 }
                             }
-                            const unsigned a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]);
-                            const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
                             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                             const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                             if (m < M && nb + 32 * pr < N)   // N % 32 == 0: a tile pair is entirely inside or outside
@@ -614,19 +619,22 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
                 va += f32x4{bf_lo(x0[0]), bf_hi(x0[0]), bf_lo(x1[0]), bf_hi(x1[0])};
                 vb += f32x4{bf_lo(x0[1]), bf_hi(x0[1]), bf_lo(x1[1]), bf_hi(x1[1])};
             }
+            const unsigned a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]);
+            const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
             if constexpr ((EPI & EPI_ROWSTAT) != 0) {
-                // row block blk of the batch = (j >> 1) (UPB == 4: units 4b..4b+3 = row blocks 2b, 2b+1, two units each)
+                // of the STORED values (see epilogue_tile). Row block blk of the batch = (j >> 1) (UPB == 4: units
+                // 4b..4b+3 = row blocks 2b, 2b+1, two units each)
+                const f32x4 ra = {bf_lo(a0), bf_hi(a0), bf_lo(a1), bf_hi(a1)};
+                const f32x4 rb = {bf_lo(b0), bf_hi(b0), bf_lo(b1), bf_hi(b1)};
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    s1 += va[e] + vb[e];
-                    s2 = fmaf(va[e], va[e], fmaf(vb[e], vb[e], s2));
+                    s1 += ra[e] + rb[e];
+                    s2 = fmaf(ra[e], ra[e], fmaf(rb[e], rb[e], s2));
                 }
                 if ((j & 1) == 0) { st_sum[j >> 1] = s1; st_sq[j >> 1] = s2; }
                 else { st_sum[j >> 1] += s1; st_sq[j >> 1] += s2; }
             }
-            const unsigned a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]);
-            const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
             const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
             outv[j] = u32x4{s0[0], s1[0], s0[1], s1[1]};

@@ -116,13 +116,18 @@ int cogs_k_cosine(hipStream_t st, const float* a, const float* b, int n, int D, 
 
 // time-aware k-means
 int cogs_k_kmeans_sqdist(hipStream_t st, int dtype, const void* feats, int T, long PD, const float* centres,
-                         const int* centre_rows, int K, float* partial, int nslices, float* dist2);
+                         const int* centre_rows, int K, float* ws, int nslices, float* dist2);
+int cogs_k_kmeans_pp_step(hipStream_t st, int dtype, const void* feats, int T, long PD, int row, int first,
+                          float* nearest2, float* probs_host, float* ws, int nslices);
+int cogs_k_kmeans_lloyd(hipStream_t st, int dtype, const void* feats, const float* ts, int T, long PD, int K, float alpha,
+                        int max_iter, float tol, const int* pool_host, int pool_len, float* centres, float* centre_ts,
+                        int64_t* assign, int* iterations, int* reseeds_used, int* exhausted, float* ws, int nslices);
 size_t cogs_k_kmeans_ws(int T, long PD, int K, int* nslices);
 int cogs_k_kmeans_assign(hipStream_t st, const float* dist2, const float* ts, const float* centre_ts, int T, int K,
                          float alpha, int64_t* assign, int* counts);
 int cogs_k_kmeans_update(hipStream_t st, int dtype, const void* feats, const float* ts, int T, long PD, int K,
                          const int64_t* assign, const int* reseed_rows, float* centres, float* centre_ts,
-                         float* shift_partial, int nblk, float* shift_out);
+                         float* ws, int nblk, float* shift_out);
 int cogs_k_kmeans_update_blocks(long PD);
 
 // LLM helpers

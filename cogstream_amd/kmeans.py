@@ -34,14 +34,13 @@ def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int
     K, PD = cluster_num, P * D
     ws = ops.kmeans_workspace(T, PD, K, dev)
 
-    # ---- k-means++ on feature distance only (:41-62) ----
+    # ---- k-means++ on feature distance only (:41-62): one device step + one pinned read of the [T] distances per
+    # centre; the draw itself is the reference's torch.multinomial on the CPU generator ----
     idx: List[int] = [random.randint(0, T - 1)]
-    nearest2 = None
+    nearest2 = torch.empty(T, dtype=torch.float32, device=dev)
+    probs = torch.empty(T, dtype=torch.float32).pin_memory()
     while len(idx) < K:
-        row = torch.tensor([idx[-1]], dtype=torch.int32, device=dev)
-        d2 = ops.kmeans_sqdist(x, None, row, 1, ws)[:, 0]          # distance^2 to the newest centre
-        nearest2 = d2 if nearest2 is None else torch.minimum(nearest2, d2)
-        probs = nearest2.cpu()                                       # (sqrt(d2))**2 of the reference
+        ops.kmeans_pp_step(x, idx[-1], len(idx) == 1, nearest2, probs, ws)     # (sqrt(d2))**2 of the reference
         s = probs.sum()
         if s.item() == 0:
             new = random.randint(0, T - 1)
@@ -53,24 +52,30 @@ def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int
     centres = ops.pack_rows(x.index_select(0, rows), torch.float32, PD) if x.dtype != torch.float32 \
         else x.index_select(0, rows).contiguous()
     centre_ts = ts.index_select(0, rows).contiguous()
-    assign = None
-    zeros = torch.zeros(K, dtype=torch.int32, device=dev)
-    last_stats["kpp_passes"], last_stats["iterations"] = K - 1, 0
-    for _ in range(max_iteration):
-        last_stats["iterations"] += 1
-        d2 = ops.kmeans_sqdist(x, centres, None, K, ws)
-        assign, counts = ops.kmeans_assign(d2, ts, centre_ts, float(alpha))
-        empty = (counts.cpu() == 0).nonzero().flatten().tolist()
-        if empty:
-            reseed = [0] * K
-            for k in empty:                                          # ascending i, one draw each (:116-120)
-                reseed[k] = random.randint(0, T - 1)
-            reseed_t = torch.tensor(reseed, dtype=torch.int32, device=dev)
-        else:
-            reseed_t = zeros
-        shift = ops.kmeans_update(x, ts, assign, reseed_t, centres, centre_ts, ws)
-        if float(shift) <= tol:
+    assign = torch.empty(T, dtype=torch.int64, device=dev)
+    # ---- Lloyd iterations (:71-131) run inside the library (one host read per iteration). Empty clusters are reseeded
+    # with random.randint(0, T-1) per cluster in ascending order (:116-120): the values are drawn AHEAD into a pool the
+    # device consumes in that order, and the generator is then put back to where the reference would have left it
+    # (state restored, the used number of draws replayed) ----
+    state = random.getstate()
+    left, done, used_total, pool_n = max_iteration, 0, 0, 2 * K
+    drawn: List[int] = []
+    while left > 0:
+        drawn.extend(random.randint(0, T - 1) for _ in range(pool_n))
+        it, used, exhausted = ops.kmeans_lloyd(x, ts, centres, centre_ts, assign, float(alpha), left, float(tol),
+                                               drawn[used_total:], ws)
+        done, left, used_total = done + it, left - it, used_total + used
+        if not exhausted:
             break
+        pool_n = min(4096, max(pool_n * 2, K))     # an iteration wanted more reseeds than were left: draw more, go on
+        drawn = drawn[:used_total]
+        random.setstate(state)
+        for _ in range(used_total):
+            random.randint(0, T - 1)
+    random.setstate(state)
+    for _ in range(used_total):
+        random.randint(0, T - 1)
+    last_stats["kpp_passes"], last_stats["iterations"] = K - 1, done
     return centres.view(K, P, D), centre_ts, assign
 
 

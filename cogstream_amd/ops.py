@@ -213,6 +213,30 @@ def kmeans_update(feats, ts, assign, reseed_rows, centres, centre_ts, ws) -> tor
     return shift
 
 
+def kmeans_pp_step(feats, row: int, first: bool, nearest2: torch.Tensor, probs_host: Optional[torch.Tensor], ws) -> None:
+    """cogs_kmeans_pp_step: nearest2 (device fp32 [T]) <- min(nearest2, |x - x[row]|^2); with probs_host (pinned CPU fp32
+    [T]) the result is copied there and the stream synchronised"""
+    T, PD = feats.shape
+    assert nearest2.is_cuda and nearest2.dtype == torch.float32 and nearest2.numel() == T
+    if probs_host is not None:
+        assert (not probs_host.is_cuda) and probs_host.is_pinned() and probs_host.dtype == torch.float32 and probs_host.numel() == T
+    check(L.lib.cogs_kmeans_pp_step(current_stream(), dtype_code(feats.dtype), ptr(feats), T, PD, int(row), int(bool(first)),
+                                    ptr(nearest2), ptr(probs_host), ptr(ws), ws.numel()), "cogs_kmeans_pp_step")
+
+
+def kmeans_lloyd(feats, ts, centres, centre_ts, assign, alpha: float, max_iter: int, tol: float, pool, ws):
+    """cogs_kmeans_lloyd -> (iterations completed, reseeds used, pool exhausted). pool: python list of pre-drawn rows"""
+    T, PD = feats.shape
+    K = centres.shape[0]
+    arr = (C.c_int32 * max(len(pool), 1))(*pool)
+    it, used, ex = C.c_int(0), C.c_int(0), C.c_int(0)
+    check(L.lib.cogs_kmeans_lloyd(current_stream(), dtype_code(feats.dtype), ptr(feats), ptr(ts), T, PD, K, float(alpha),
+                                  int(max_iter), float(tol), C.cast(arr, C.c_void_p), len(pool), ptr(centres), ptr(centre_ts),
+                                  ptr(assign), C.byref(it), C.byref(used), C.byref(ex), ptr(ws), ws.numel()),
+          "cogs_kmeans_lloyd")
+    return it.value, used.value, bool(ex.value)
+
+
 def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out: an int64 [1] device tensor (e.g. a slot of the generated-ids buffer) to write the index into"""
     _need_cuda(logits, out)

@@ -107,8 +107,8 @@ typedef struct {
     const int32_t* rope_rowpos;
     int rope_maxpos;
     /* LayerNorm fused around the GEMM (nn.LayerNorm of modeling_videollama3_encoder.py:382-391; bf16/f32 alike):
-     * row_stats != NULL: the GEMM also writes, per output row and 64-column block, (sum, sum of squares) of its fp32
-     *   results: row_stats [M][N/64][2] fp32 (N % 64 == 0, no SWIGLU / fp32 output); cogs_ln_finalize turns them into
+     * row_stats != NULL: the GEMM also writes, per output row and 64-column block, (sum, sum of squares) of the values
+     *   it stores (after the rounding to `dtype`): row_stats [M][N/64][2] fp32 (N % 64 == 0, no SWIGLU / fp32 output); cogs_ln_finalize turns them into
      *   ln_ab [M][2] = (rstd, -rstd * mean).
      * ln_ab != NULL: the GEMM computes LN(A) . W0^T + bias0 WITHOUT a normalised copy of A. What the kernels evaluate
      *   is exactly  y[r][n] = ln_ab[r][0] * acc[r][n] + col_c[n]  (before rope / activation; bias must be NULL), where
@@ -198,6 +198,24 @@ cogs_status cogs_kmeans_assign(cogs_stream stream, const float* dist2, const flo
 cogs_status cogs_kmeans_update(cogs_stream stream, int dtype, const void* feats, const float* ts, int T,
                                int64_t PD, int K, const int64_t* assign, const int32_t* reseed_rows,
                                float* centres, float* centre_ts, float* shift_out, void* ws, size_t ws_bytes);
+/* One k-means++ step (:46-60): squared distance of every row to feature row `row`, folded into nearest2 (device fp32 [T]:
+ * first != 0 stores, else min). probs_host (pinned host fp32 [T], nullable): the updated nearest2 is copied there and the
+ * stream is synchronised, so the caller can draw the next centre (torch.multinomial on the CPU generator) right away.
+ * Workspace: cogs_kmeans_workspace_bytes(T, PD, 1). */
+cogs_status cogs_kmeans_pp_step(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD, int row, int first,
+                                float* nearest2, float* probs_host, void* ws, size_t ws_bytes);
+/* The whole Lloyd loop (:71-131) from given centres: per iteration distances -> assignment -> means / reseeds -> centre
+ * shift, stopping after max_iter iterations or when the shift is <= tol. The loop synchronises the stream once per
+ * iteration to read the shift (8 bytes written by the last kernel into host-mapped memory); nothing else crosses.
+ * Empty clusters (:116-120: one random.randint(0, T-1) per empty cluster, ascending cluster index, every iteration) take
+ * their rows from reseed_pool (HOST int32 [pool_len], pool_len <= 4096: the caller's pre-drawn values, consumed in
+ * order; *reseeds_used reports how many). If an iteration needs more than are left it is NOT committed: the call
+ * returns COGS_OK with *pool_exhausted = 1 and *iterations = the completed ones; draw more and call again with the
+ * remaining iteration budget. T <= 16 384. Workspace: cogs_kmeans_workspace_bytes(T, PD, K). */
+cogs_status cogs_kmeans_lloyd(cogs_stream stream, int dtype, const void* feats, const float* ts, int T, int64_t PD, int K,
+                              float alpha, int max_iter, float tol, const int32_t* reseed_pool, int pool_len,
+                              float* centres, float* centre_ts, int64_t* assign, int* iterations, int* reseeds_used,
+                              int* pool_exhausted, void* ws, size_t ws_bytes);
 /* dtype conversion / zero-padded row copy (features.to(float32), patch padding) */
 cogs_status cogs_pack_rows(cogs_stream stream, int in_dtype, int out_dtype, const void* in, int64_t ld_in,
                            void* out, int64_t ld_out, int rows, int cols_in, int cols_out);

@@ -578,12 +578,19 @@ def test_gemm_row_stats_and_ln_fold(dev, M):
     part = torch.zeros(M, H // 64, 2, device=dev)
     x = ops.gemm(a0.to(dev), w0.to(dev), b0.to(dev), residual=res.to(dev), row_stats=part)
     assert rel_err(x.float(), y32) < 1.2e-2
-    want = torch.stack([y32.view(M, H // 64, 64).sum(-1), (y32 ** 2).view(M, H // 64, 64).sum(-1)], -1)
-    assert rel_err(part, want) < 1e-4
+    xs = x.float().cpu()                                                 # the statistics are those of the STORED rows
+    want = torch.stack([xs.view(M, H // 64, 64).sum(-1), (xs ** 2).view(M, H // 64, 64).sum(-1)], -1)
+    assert rel_err(part, want) < 1e-5
     ab = ops.ln_finalize(part, H, eps)
-    mean, var = y32.mean(1), y32.var(1, unbiased=False)
+    mean, var = xs.double().mean(1).float(), xs.double().var(1, unbiased=False).float()
     rstd = (var + eps).rsqrt()
-    assert rel_err(ab[:, 0], rstd) < 1e-4 and rel_err(ab[:, 1], -rstd * mean) < 1e-4
+    # rows dominated by their mean (|mean / std| ~ 100) lose (mean/std)^2 of the fp32 partial sums' precision in
+    # E[x^2] - mean^2: 1e-3 there, 1e-4 everywhere else -- both far below the bf16 rounding of the consumer's output
+    huge_rows = torch.zeros(M, dtype=torch.bool)
+    huge_rows[3::11] = True
+    abc = ab.cpu()
+    for rows, tol in ((~huge_rows, 1e-4), (huge_rows, 1e-3)):
+        assert rel_err(abc[rows, 0], rstd[rows]) < tol and rel_err(abc[rows, 1], (-rstd * mean)[rows]) < tol
     # consumer: fc1-like (GELU) and plain
     gamma, beta = (1 + 0.3 * torch.randn(H)).bfloat16(), (0.2 * torch.randn(H)).bfloat16()
     w1 = (torch.randn(N2, H) / 30).bfloat16()
