@@ -35,7 +35,11 @@ def lora_linear(x, w, name: str, lora: Optional[Dict[str, torch.Tensor]], scalin
     """nn.Linear `name` of the state dict w, plus -- if the adapter targets it -- the UNMERGED low-rank branch of
     peft==0.15.2 (environment.yml:335) `lora.Linear.forward` in eval mode: result + lora_B(lora_A(x)) * scaling,
     scaling = lora_alpha / r (second_stage_training.py:257-264: r = 8, alpha = 16). peft is not installed in the
-    build container, so this branch is restated from its published algorithm and is unpinned."""
+    build container (and cannot be: no network), so this branch is restated from its published algorithm. It is pinned
+    by tests/golden/lora.npz -- the reference's own model object with the linears of the reference's target-module
+    list (second_stage_training.py:241-254) wrapped by independently written nn.Linear-based modules computing that
+    forward (tests/golden/make_golden.py::golden_lora) -- i.e. pinned to an independent evaluation inside the reference
+    model, not to peft's code."""
     y = F.linear(x, w[name + ".weight"], w.get(name + ".bias"))
     if lora is not None and (name + ".lora_A.weight") in lora:
         y = y + F.linear(F.linear(x, lora[name + ".lora_A.weight"]), lora[name + ".lora_B.weight"]) * scaling

@@ -370,6 +370,86 @@ def golden_qwen2():
     save("qwen2.npz", **out)
 
 
+class _PeftStyleLoRALinear(torch.nn.Module):
+    """peft 0.15.2 `lora.Linear.forward` in eval mode, written out with nn.Linear modules (peft itself is not installed in
+    this image and cannot be): result = base(x) + lora_B(lora_A(dropout(x))) * (lora_alpha / r), dropout = identity in
+    eval mode, both low-rank maps bias-free (LoraConfig(bias="none"), train/second_stage_training.py:257-264)."""
+
+    def __init__(self, base: torch.nn.Linear, A: torch.Tensor, B: torch.Tensor, alpha: float):
+        super().__init__()
+        r = A.shape[0]
+        self.base_layer = base
+        self.lora_dropout = torch.nn.Dropout(p=0.1)
+        self.lora_A = torch.nn.Linear(base.in_features, r, bias=False)
+        self.lora_B = torch.nn.Linear(r, base.out_features, bias=False)
+        self.lora_A.weight.data.copy_(A)
+        self.lora_B.weight.data.copy_(B)
+        self.scaling = alpha / r
+
+    def forward(self, x):
+        return self.base_layer(x) + self.lora_B(self.lora_A(self.lora_dropout(x))) * self.scaling
+
+
+def golden_lora():
+    """LoRA branch. The REFERENCE's model object (Videollama3Qwen2ForCausalLM, tiny) with the
+    linears of the reference's target-module list (train/second_stage_training.py:241-254: q/k/v/o/gate/up/down of
+    every decoder layer + mm_projector.readout.0/.2) wrapped by _PeftStyleLoRALinear, r = 8, lora_alpha = 16 (:257-264),
+    eval mode. Stored: the projector output and the Qwen2 last_hidden_state / last-row logits for the base model and for
+    two adapters (the reference loads two: 'full_module' and 'language_module', evaluate/answer_generate.py:181-182).
+    peft itself could not be run here (not installed, no network): this pins the restated branch of oracle/qwen2.py and
+    the merged-weight path of cogstream_amd.weights.merge_lora to an evaluation by independent modules inside the
+    reference's own model, not to peft's code."""
+    from cogstream_amd.weights import random_lora_state
+    lcfg, vcfg = LlmConfig(**LLM), VisionConfig(**VIT)
+    lst = random_llm_state(lcfg, seed=7, std=0.05)
+    vst = random_vit_state(vcfg, seed=3, std=0.05)
+    pst = random_proj_state(VIT["hidden_size"], LLM["hidden_size"], seed=1, std=0.05)
+    g = torch.Generator().manual_seed(4242)
+    S, M = 37, 24
+    embeds = torch.randn(S, LLM["hidden_size"], generator=g) * 0.5
+    vis = torch.randn(M, VIT["hidden_size"], generator=g) * 0.5
+    targets = []
+    for i in range(LLM["num_hidden_layers"]):                     # second_stage_training.py:241-250
+        targets.extend([f"model.layers.{i}.self_attn.q_proj", f"model.layers.{i}.self_attn.k_proj",
+                        f"model.layers.{i}.self_attn.v_proj", f"model.layers.{i}.self_attn.o_proj",
+                        f"model.layers.{i}.mlp.gate_proj", f"model.layers.{i}.mlp.up_proj", f"model.layers.{i}.mlp.down_proj"])
+    targets.extend(["model.mm_projector.readout.0", "model.mm_projector.readout.2"])       # :251-254
+    out = {"embeds": embeds, "vis": vis, "targets": np.array(json.dumps(targets)), "r": np.int64(8), "lora_alpha": np.float64(16.0),
+           "llm_checksum": np.float64(checksum(lst))}
+
+    def run(model, tag):
+        with torch.no_grad():
+            r = model.get_model()(inputs_embeds=embeds[None], attention_mask=torch.ones(1, S, dtype=torch.long))
+            hid = r.last_hidden_state[0]
+            out[f"{tag}_hidden"] = hid
+            out[f"{tag}_logits"] = model.lm_head(hid[-1:])[0]
+            out[f"{tag}_projected"] = model.get_model().mm_projector(vis)
+
+    run(build_ref_model(vst, pst, lst), "base")
+    for a, seed in (("full_module", 21), ("language_module", 22)):
+        lora = random_lora_state(lcfg, seed=seed, r=8, proj_dims=(VIT["hidden_size"], LLM["hidden_size"]))
+        out[f"{a}_seed"] = np.int64(seed)
+        out[f"{a}_checksum"] = np.float64(checksum(lora))
+        model = build_ref_model(vst, pst, lst)
+        n_wrapped = 0
+        for name in targets:
+            parent_name, _, leaf = name.rpartition(".")
+            parent = model.get_submodule(parent_name)
+            base = getattr(parent, leaf) if not leaf.isdigit() else parent[int(leaf)]
+            assert isinstance(base, torch.nn.Linear), name
+            key = "base_model.model." + name
+            wrapped = _PeftStyleLoRALinear(base, lora[key + ".lora_A.weight"], lora[key + ".lora_B.weight"], 16.0)
+            if leaf.isdigit():
+                parent[int(leaf)] = wrapped
+            else:
+                setattr(parent, leaf, wrapped)
+            n_wrapped += 1
+        assert n_wrapped == len(targets) == 7 * LLM["num_hidden_layers"] + 2 and 2 * n_wrapped == len(lora)
+        run(model.eval(), a)
+        print(a, "logits moved by", float((out[f"{a}_logits"] - out["base_logits"]).abs().max() / out["base_logits"].abs().max()))
+    save("lora.npz", **out)
+
+
 def golden_vit_bf16():
     """the encoder + projector cast to bf16 (evaluate/answer_generate.py:176), block-diagonal semantics (one frame
     per call of the eager path = the flash path), on the inputs of vit_tiny.npz rounded to bf16 (:70)."""

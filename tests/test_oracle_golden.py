@@ -153,6 +153,54 @@ def test_merge_lora_equals_unmerged_branch_fp32():
     assert rel_err(a, oq.forward(st, emb, **kw)[0]) > 0.05
 
 
+def _lora_case():
+    import json as _json
+    from cogstream_amd.weights import (LlmConfig, VisionConfig, random_llm_state, random_lora_state, random_proj_state,
+                                       random_vit_state)
+    g = _load("lora.npz")
+    lcfg = LlmConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                     num_key_value_heads=1, vocab_size=512, image_token_index=258, eos_token_id=257)
+    lst = random_llm_state(lcfg, seed=7, std=0.05)
+    pst = random_proj_state(576, 256, seed=1, std=0.05)
+    assert abs(float(sum(v.double().abs().sum() for v in lst.values())) - float(g["llm_checksum"])) < 1e-6
+    loras = {}
+    for a in ("full_module", "language_module"):
+        lo = random_lora_state(lcfg, seed=int(g[f"{a}_seed"]), r=int(g["r"]), proj_dims=(576, 256))
+        assert abs(float(sum(v.double().abs().sum() for v in lo.values())) - float(g[f"{a}_checksum"])) < 1e-6
+        loras[a] = lo
+    targets = _json.loads(str(g["targets"]))
+    return g, lcfg, lst, pst, loras, targets
+
+
+def test_lora_branch_matches_the_reference_model_with_peft_style_modules():
+    """tests/golden/lora.npz: the REFERENCE's model object with every linear of the reference's target-module list
+    (train/second_stage_training.py:241-254) wrapped by an independently written module computing peft's published
+    eval-mode forward, base(x) + lora_B(lora_A(x)) * (lora_alpha / r), r = 8, alpha = 16 (:257-264). Pins (a) the
+    restated unmerged branch of oracle/qwen2.py::lora_linear, (b) weights.merge_lora (what the product loads) and (c)
+    the adapter key layout / target list. peft's own code could not be run in this image (not installed)."""
+    from oracle import qwen2 as oq
+    from oracle import vision as ov
+    from cogstream_amd.weights import LORA_LLM_TARGETS, merge_lora
+    g, lcfg, lst, pst, loras, targets = _lora_case()
+    assert sorted(targets) == sorted([f"model.layers.{i}.{t}" for i in range(2) for t in LORA_LLM_TARGETS] +
+                                     ["model.mm_projector.readout.0", "model.mm_projector.readout.2"])
+    kw = dict(heads=2, kv_heads=1, layers=2)
+    emb, vis = torch.from_numpy(g["embeds"]), torch.from_numpy(g["vis"])
+    scaling = float(g["lora_alpha"]) / int(g["r"])
+    base = oq.forward(lst, emb, **kw)[0]
+    assert rel_err(base, torch.from_numpy(g["base_hidden"])) < 2e-5
+    assert rel_err(ov.project(pst, vis), torch.from_numpy(g["base_projected"])) < 2e-5
+    for a, lo in loras.items():
+        strip = {k.replace("base_model.model.model.", ""): v for k, v in lo.items()}
+        hid = oq.forward(lst, emb, lora=strip, lora_scaling=scaling, **kw)[0]                  # (a) unmerged branch
+        assert rel_err(hid, torch.from_numpy(g[f"{a}_hidden"])) < 2e-5
+        assert rel_err(oq.logits(lst, hid[-1]), torch.from_numpy(g[f"{a}_logits"])) < 2e-5
+        ml, mp = merge_lora(lst, pst, lo, lcfg, lora_alpha=float(g["lora_alpha"]))             # (b) merged weights
+        assert rel_err(oq.forward(ml, emb, **kw)[0], torch.from_numpy(g[f"{a}_hidden"])) < 2e-5
+        assert rel_err(ov.project(mp, vis), torch.from_numpy(g[f"{a}_projected"])) < 2e-5
+        assert rel_err(torch.from_numpy(g[f"{a}_hidden"]), torch.from_numpy(g["base_hidden"])) > 0.05   # the adapter acts
+
+
 def _qwen2_case(g, tag):
     import json as _json
     from cogstream_amd.weights import LlmConfig, random_llm_state
