@@ -90,15 +90,18 @@ def stage_rooflines(c3, mm3, dev):
     from cogstream_amd import kmeans as km
     from cogstream_amd import ops
 
-    def timed(fn, n=5):
+    def timed(fn, n=5, reps=1):
+        """median over n samples of (reps back-to-back calls + one synchronise) / reps: with reps > 1 the per-call
+        launch + synchronise latency of a 10 us kernel does not pass for its duration"""
         fn()
         torch.cuda.synchronize()
         ts = []
         for _ in range(n):
             t0 = time.perf_counter()
-            r = fn()
+            for _ in range(reps):
+                r = fn()
             torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
+            ts.append((time.perf_counter() - t0) / reps)
         return r, sorted(ts)[len(ts) // 2]
 
     T3 = 256
@@ -126,18 +129,19 @@ def stage_rooflines(c3, mm3, dev):
     gh3, gw3 = c3["gh"], c3["gw"]
     Pm = gh3 * gw3 // 4
     minor = torch.zeros(T3, dtype=torch.uint8, device=dev)
-    _, t_pd = timed(lambda: ops.pixdiff_mask(pix3, T3, Pm, 0.1, 1, minor), 20)
+    _, t_pd = timed(lambda: ops.pixdiff_mask(pix3, T3, Pm, 0.1, 1, minor), 5, reps=50)
     out.append(hbm_stage("_get_compression_mask (A12)", "pixdiff_kernel (csrc/compress.hip)",
                          "model/cogreasoner_chat.py:383-432", pix3.numel() * pix3.element_size(), t_pd,
-                         f"pixel_values [{pix3.shape[0]},588] bf16 read once, uint8 mask [{T3 * Pm}] written"))
+                         f"pixel_values [{pix3.shape[0]},588] bf16 read once, uint8 mask [{T3 * Pm}] written; two launches "
+                         f"(difference + per-frame fix-up), 50 calls back to back per sample"))
     # compaction + splice: every prompt row is one gathered row (embedding table or visual token), cogs_gather_rows
     S = mm3.shape[0] + 2048
     table = torch.randn(4096, D, device=dev, dtype=mm3.dtype)
     idx = torch.cat([torch.arange(2048, device=dev), -torch.arange(1, mm3.shape[0] + 1, device=dev)]).to(torch.int64)
-    _, t_g = timed(lambda: ops.gather_rows(table, mm3, idx), 20)
+    _, t_g = timed(lambda: ops.gather_rows(table, mm3, idx), 5, reps=50)
     out.append(hbm_stage("_compress_visual_tokens + prepare_inputs_labels_for_multimodal (A13-A14)",
                          "gather_rows_kernel (csrc/compress.hip)", "model/cogreasoner_chat.py:449-476,567-572",
-                         2 * S * D * es, t_g, f"{S} prompt rows of {D} bf16 read + written once"))
+                         2 * S * D * es, t_g, f"{S} prompt rows of {D} bf16 read + written once; 50 calls back to back per sample"))
     return out
 
 
