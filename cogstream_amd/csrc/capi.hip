@@ -9,6 +9,8 @@
 #include <stdint.h>
 #include <new>
 #include <stdlib.h>
+#include <dlfcn.h>
+#include <atomic>
 #include <string.h>
 #include <vector>
 
@@ -615,6 +617,33 @@ static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* p
         }
     }
     return COGS_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU
+// RCCL is bound at first use: libcogs_hip.so itself does not link against it (a single-GPU user never loads it)
+typedef int (*cogs_nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static cogs_nccl_allgather_fn cogs_bind_allgather() {
+    static std::atomic<int> state{0};      // 0 = not tried, 1 = bound, -1 = unavailable
+    static cogs_nccl_allgather_fn fn = nullptr;
+    const int s = state.load(std::memory_order_acquire);
+    if (s != 0) return s > 0 ? fn : nullptr;
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    cogs_nccl_allgather_fn f = lib ? (cogs_nccl_allgather_fn)dlsym(lib, "ncclAllGather") : nullptr;
+    fn = f;
+    state.store(f ? 1 : -1, std::memory_order_release);
+    return f;
+}
+cogs_status cogs_allgather_tokens(cogs_stream stream, void* nccl_comm, const void* local, size_t local_rows,
+                                  size_t row_bytes, void* global) {
+    if (!nccl_comm || !local || !global || local_rows == 0 || row_bytes == 0) return COGS_E_INVALID;
+    cogs_nccl_allgather_fn f = cogs_bind_allgather();
+    if (!f) return COGS_E_UNSUPPORTED;
+    const int nccl_uint8 = 1;              // ncclUint8 (rccl.h): the payload is moved as bytes, whatever its dtype
+    return f(local, global, local_rows * row_bytes, nccl_uint8, nccl_comm, (hipStream_t)stream) == 0 ? COGS_OK : COGS_E_HIP;
 }
 
 cogs_status cogs_proj_load(cogs_handle h, const cogs_proj_weights* w) {

@@ -1,8 +1,18 @@
 """Frame sharding of the encoder over the GPUs of one node (build-only, the reference
 never shards a clip). Legal because block-diagonal attention, RoPE and the 2x2 merge are all per frame
-(model/modeling_videollama3_encoder.py:309-312,427,487-501): rank r encodes a contiguous slice of frames,
-one all-gather (RCCL over xGMI on the GPU, gloo in the CPU tests) reassembles the [M,1152] visual tokens in
-frame order. One process per GPU; no other data-path collective."""
+(model/modeling_videollama3_encoder.py:309-312,427,487-501): rank r encodes AND PROJECTS a contiguous slice of
+frames, one all-gather (RCCL over xGMI on the GPU, gloo in the CPU tests; `cogs_allgather_tokens` is the C-ABI form)
+reassembles the projected [M, 3584] visual tokens in frame order. One process per GPU; no other data-path collective.
+
+Why the gather carries the 3584-wide PROJECTED tokens and not the 1152-wide encoder output (SURVEY 8e budgets the
+narrow form: 29.5 MB instead of 91.7 MB at cfg3): the consumer needs projected tokens, so the choice is between
+  narrow gather + projector on all M tokens at the consumer:  3.7 MB per link (~0.04 ms at ~100 GB/s per xGMI link, the
+      7 shards arrive over 7 links in parallel) + 0.41 ms (the two projector GEMMs at M = 12 800, rocprofv3), and
+  projector on the rank's own M/8 tokens + wide gather:        0.13 ms (M = 1 600) + 11.5 MB per link (~0.12 ms).
+The wide form is ~0.2 ms shorter per clip and does the projector's 0.43 TFLOP once instead of on every consumer; either
+way the collective is < 4 % of a rank's 5.9 ms share of the clip. (Link rate is the guide's 7 x ~153 GB/s peak derated
+to ~100 GB/s; no multi-GPU node was available to the builder, so these are estimates -- the driver's N = 2/4/8 runs of
+bench.py measure the real thing.)"""
 from __future__ import annotations
 
 from typing import List, Tuple

@@ -284,6 +284,20 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
                             const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
                             void* out_tokens, void* ws, size_t ws_bytes);
 
+/* ----------------------------------------------------------------------- multi-GPU ------ */
+
+/* The one data-path collective of the path (the reference never shards a clip, its only
+ * distributed code is init + per-video replicas, evaluate/answer_generate.py:155,186-187): frames of a clip are encoded
+ * (and projected) by the ranks of one node, and ONE all-gather reassembles the visual tokens in frame order. Every rank
+ * contributes `local_rows` rows of `row_bytes` bytes (equal counts: a ragged frame split pads to the largest shard);
+ * `global` receives world * local_rows rows in rank order. `nccl_comm` is an ncclComm_t the caller created (rccl.h; one
+ * process per GPU); the call enqueues ncclAllGather on `stream`. librccl.so is bound lazily with dlopen -- the library
+ * has no link-time dependency on it -- and COGS_E_UNSUPPORTED is returned when it cannot be loaded. In-place use
+ * (local == global + rank * local_rows * row_bytes) is allowed, as for ncclAllGather. The Python host does the same
+ * through torch.distributed (cogstream_amd/parallel.py), whose "nccl" backend is RCCL. */
+cogs_status cogs_allgather_tokens(cogs_stream stream, void* nccl_comm, const void* local, size_t local_rows,
+                                  size_t row_bytes, void* global);
+
 /* MlpGeluProjector (model/cogreasoner_chat.py:199-211): Linear -> GELU(erf) -> Linear */
 typedef struct {
     int dtype; int in_dim, out_dim;

@@ -365,3 +365,38 @@ def test_reference_driver_call_sequence_under_the_reference_names(dev, tmp_path)
         model.set_adapter(name)
         lg[name] = model.llm.forward(emb)["logits"].clone()
     assert rel_err(lg["full_module"], lg["base"]) > 1e-3 and rel_err(lg["language_module"], lg["full_module"]) > 1e-3
+
+
+def test_c_abi_allgather_over_rccl_single_rank(dev):
+    """cogs_allgather_tokens (the C-ABI form of the path's one collective) on a real RCCL
+    communicator: this box has one GPU, so the communicator has one rank -- what is checked is the binding (librccl is
+    loaded lazily, the call lands on ncclAllGather with a byte payload on the caller's stream) and the argument
+    checks. The N > 1 data movement is RCCL's own; the frame-order bookkeeping around it is covered by the gloo tests
+    (tests/test_distributed_cpu.py) and the two-rank HIP rehearsal above."""
+    import ctypes as C
+    from cogstream_amd import _lib as L
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("librccl not present")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        local = torch.randn(1600, 3584, device=dev).to(BF)                 # one rank's cfg3 share: 32 frames x 50 tokens
+        out = torch.zeros_like(local)
+        rc = L.lib.cogs_allgather_tokens(L.current_stream(), comm, local.data_ptr(), local.shape[0], local.shape[1] * 2,
+                                         out.data_ptr())
+        torch.cuda.synchronize()
+        assert rc == L.OK and torch.equal(out, local)
+        assert L.lib.cogs_allgather_tokens(L.current_stream(), None, local.data_ptr(), 1600, 7168, out.data_ptr()) == L.E_INVALID
+        assert L.lib.cogs_allgather_tokens(L.current_stream(), comm, local.data_ptr(), 0, 7168, out.data_ptr()) == L.E_INVALID
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
