@@ -279,7 +279,10 @@ def main() -> None:
         "config": {"workload": f"{'cfg3 (BASELINE configs[2])' if cfg3 else ('cfg2 (BASELINE configs[1])' if T == 64 else 'cfg2-sized frames')}: "
                                f"{T}x480x854 '{args.clip}' clip -> {gh * 14}x{gw * 14}, "
                                f"{n_patches} patches, {m_tokens} visual tokens; ViT(1152x27, hd72)+projector(3584); "
-                               f"random-init weights",
+                               f"random-init weights"
+                               + (f"; WEAK scaling over {world} GPUs (the clip grows with N at {t_loc} frames per GPU -- "
+                                  f"BASELINE configs[2]'s fixed 256-frame clip, strong scaling, is this line's 'cfg3' key)" if weak else
+                                  (f"; STRONG scaling over {world} GPUs ({t_loc} frames per GPU)" if world > 1 else "")),
                    "scaling_note": ("WEAK scaling: the clip grows with N (64 frames per GPU); the strong-scaling curve of the "
                                     "fixed 256-frame configs[2] clip is the 'cfg3' key of this line") if weak else
                                    ("strong scaling of one fixed clip" if world > 1 else "single GPU"),
@@ -306,7 +309,7 @@ def main() -> None:
         # passes: FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction). The figure is read from the
         # PMC summary of the same command committed under profiles/ (tools/collect_profiles.sh), and labelled so.
         traffic, traffic_src = None, None
-        for name in ("r2_gemm_traffic.json", "r1_g_gemm_traffic.json"):
+        for name in ("r3_gemm_traffic.json", "r2_gemm_traffic.json", "r1_g_gemm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if world == 1 and T == 64 and not cfg3 and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")

@@ -18,6 +18,14 @@ import torch
 from . import ops
 
 last_stats = {"kpp_passes": 0, "iterations": 0}    # of the most recent call (bench.py: bytes moved per stage)
+_pinned = {}                                        # T -> pinned host fp32 [T] (page-locking costs ~0.1 ms: done once)
+
+
+def _pinned_probs(T: int) -> torch.Tensor:
+    buf = _pinned.get(T)
+    if buf is None:
+        buf = _pinned[T] = torch.empty(T, dtype=torch.float32).pin_memory()
+    return buf
 
 
 def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int, alpha: float = 2,
@@ -38,7 +46,7 @@ def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int
     # centre; the draw itself is the reference's torch.multinomial on the CPU generator ----
     idx: List[int] = [random.randint(0, T - 1)]
     nearest2 = torch.empty(T, dtype=torch.float32, device=dev)
-    probs = torch.empty(T, dtype=torch.float32).pin_memory()
+    probs = _pinned_probs(T)
     while len(idx) < K:
         ops.kmeans_pp_step(x, idx[-1], len(idx) == 1, nearest2, probs, ws)     # (sqrt(d2))**2 of the reference
         s = probs.sum()

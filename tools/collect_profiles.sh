@@ -6,15 +6,15 @@
 #   5. SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE (matrix-pipe busy share per kernel)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/enc -- python3 $R/bench.py --steps 3 --warmup 1 --no-llm --no-cpu --no-cfg3 > $OUT/enc.json 2> $OUT/enc.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/enc -- python3 $R/bench.py --steps 3 --warmup 1 --no-llm --no-cpu --no-cfg3 --emulate-shard 0 > $OUT/enc.json 2> $OUT/enc.err
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/full -- python3 $R/bench.py --steps 3 --warmup 1 > $OUT/full.json 2> $OUT/full.err
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-llm --no-cpu --no-cfg3 > /dev/null 2> $OUT/fetch.err
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 1 --warmup 0 --no-llm --no-cpu --no-cfg3 > /dev/null 2> $OUT/write.err
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -- python3 $R/bench.py --steps 1 --warmup 0 --no-llm --no-cpu --no-cfg3 > /dev/null 2> $OUT/mfma.err
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-llm --no-cpu --no-cfg3 --emulate-shard 0 > /dev/null 2> $OUT/fetch.err
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 1 --warmup 0 --no-llm --no-cpu --no-cfg3 --emulate-shard 0 > /dev/null 2> $OUT/write.err
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -- python3 $R/bench.py --steps 1 --warmup 0 --no-llm --no-cpu --no-cfg3 --emulate-shard 0 > /dev/null 2> $OUT/mfma.err
 F=$(find $OUT/fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/write -name "*counter_collection.csv" | head -1)
 python3 $R/tools/traffic_from_pmc.py $F $W > $OUT/gemm_traffic.json
 python3 $R/tools/mfma_busy.py $OUT/mfma > $OUT/pmc_mfma_busy.txt
