@@ -7,9 +7,17 @@ import random
 import torch
 
 
-def kmeans_with_time_min_max(features, timestamp, cluster_num, alpha=2, max_iteration=30, tol=1e-4):
+def kmeans_with_time_min_max(features, timestamp, cluster_num, alpha=2, max_iteration=30, tol=1e-4,
+                             exact_distances: bool = False):
     """Restates kmeans_with_time.py:4-137 step by step; RNG: python `random` for the first centre and
-    reseeds (:41,57,118), torch.multinomial on the CPU generator for the rest (:60)."""
+    reseeds (:41,57,118), torch.multinomial on the CPU generator for the rest (:60).
+    exact_distances (tie studies only, not the reference's arithmetic): torch.cdist without its matmul form, i.e. the
+    direct sum of squared differences. With more than 25 rows the reference's cdist evaluates |x|^2 + |c|^2 - 2 x.c in
+    one sgemm, whose rounding noise breaks EXACT ties between duplicate centres in an order no other implementation can
+    reproduce (tests/golden/kmeans_tie_study.py); the direct form leaves exact ties exact, and
+    argmin then takes the first centre -- as the HIP kernels do."""
+    cdist = (lambda a, b: torch.cdist(a, b, p=2, compute_mode="donot_use_mm_for_euclid_dist")) if exact_distances \
+        else (lambda a, b: torch.cdist(a, b, p=2))
     features = features.to(dtype=torch.float32)
     if not isinstance(timestamp, torch.Tensor):
         timestamp = torch.tensor(timestamp, dtype=torch.float32)
@@ -19,7 +27,7 @@ def kmeans_with_time_min_max(features, timestamp, cluster_num, alpha=2, max_iter
     x = features.reshape(T, P * D)
     idx = [random.randint(0, T - 1)]
     while len(idx) < cluster_num:
-        d = torch.cdist(x, x[idx], p=2)
+        d = cdist(x, x[idx])
         nearest, _ = d.min(dim=1)
         probs = nearest ** 2
         s = probs.sum()
@@ -31,7 +39,7 @@ def kmeans_with_time_min_max(features, timestamp, cluster_num, alpha=2, max_iter
     cf, ct = x[idx], timestamp[idx]
     assign = None
     for _ in range(max_iteration):
-        df = torch.cdist(x, cf, p=2)
+        df = cdist(x, cf)
         dt = torch.abs(timestamp.unsqueeze(1) - ct.unsqueeze(0))
         fmin, fmax = df.min(dim=1, keepdim=True).values, df.max(dim=1, keepdim=True).values
         tmin, tmax = dt.min(dim=1, keepdim=True).values, dt.max(dim=1, keepdim=True).values

@@ -151,6 +151,44 @@ def golden_kmeans():
     save("kmeans.npz", **cases)
 
 
+def golden_kmeans_reseed():
+    """the empty-cluster branch of the reference (kmeans_with_time.py:116-120: one random.randint(0, T-1) per empty
+    cluster, ascending cluster index, every iteration). Degenerate inputs -- a handful of distinct rows repeated, constant
+    time stamps -- make duplicate centres, whose later copies stay empty: case 0 reseeds three clusters once, case 1
+    seven clusters in every one of the 30 iterations (211 draws in all). Stored with the number of draws and the value
+    of random.random() right after the call, so that an implementation that pre-draws reseed rows can be held to
+    leaving the generator exactly where the reference leaves it."""
+    cases = {}
+    for ci, (T, P, D, K, seed, nd) in enumerate([(48, 2, 8, 6, 5, 3), (40, 2, 8, 10, 7, 3)]):
+        g = torch.Generator().manual_seed(500 + seed)
+        base = torch.randn(nd, P * D, generator=g) * 3
+        lab = torch.randint(0, nd, (T,), generator=g)
+        feats = base[lab].view(T, P, D).clone()
+        ts = torch.zeros(T)
+        calls = []
+        orig = random.randint
+
+        def counted(a, b, _orig=orig, _calls=calls):
+            v = _orig(a, b)
+            _calls.append(v)
+            return v
+
+        random.randint = counted
+        try:
+            random.seed(seed)
+            torch.manual_seed(seed)
+            cf, ct, assign = ref_kmeans(feats, ts, K)
+            nxt = random.random()
+        finally:
+            random.randint = orig
+        cases.update({f"c{ci}_features": feats, f"c{ci}_ts": ts, f"c{ci}_K": np.int64(K), f"c{ci}_seed": np.int64(seed),
+                      f"c{ci}_centres": cf.float(), f"c{ci}_centre_ts": ct, f"c{ci}_assign": assign,
+                      f"c{ci}_randint_calls": np.int64(len(calls)), f"c{ci}_next_random": np.float64(nxt)})
+        print("kmeans_reseed case", ci, "randint draws", len(calls), "sizes", torch.bincount(assign, minlength=K).tolist())
+    cases["n_cases"] = np.int64(2)
+    save("kmeans_reseed.npz", **cases)
+
+
 def golden_compress():
     g = torch.Generator().manual_seed(31)
     t, gh, gw, ms = 6, 4, 6, 2

@@ -61,6 +61,59 @@ def test_kmeans_vs_reference(dev, ci):
         assert assign is None
 
 
+def test_kmeans_reseed_branch_vs_reference(dev):
+    """The empty-cluster branch (kmeans_with_time.py:116-120) through cogs_kmeans_lloyd: the reseed rows are drawn AHEAD on
+    the host into a pool the device consumes in the reference's order, and the Python generator is afterwards put back
+    to where the reference leaves it. tests/golden/kmeans_reseed.npz case 0 (the reference on inputs with duplicate
+    centres: three clusters reseeded): assignments, centres and the generator position equal the reference's."""
+    from cogstream_amd.kmeans import kmeans_with_time_min_max
+    g = _load("kmeans_reseed.npz")
+    feats, ts, K, seed = torch.from_numpy(g["c0_features"]), torch.from_numpy(g["c0_ts"]), int(g["c0_K"]), int(g["c0_seed"])
+    random.seed(seed)
+    torch.manual_seed(seed)
+    cf, ct, assign = kmeans_with_time_min_max(feats.to(dev), ts, K)
+    assert random.random() == float(g["c0_next_random"])              # as many draws consumed as the reference consumed
+    assert torch.equal(assign.cpu(), torch.from_numpy(g["c0_assign"]))
+    assert rel_err(cf.float(), torch.from_numpy(g["c0_centres"])) < 1e-5
+    assert rel_err(ct.cpu() + 1, torch.from_numpy(g["c0_centre_ts"]) + 1) < 1e-6
+
+
+def test_kmeans_reseed_pool_runs_dry_and_resumes(dev, monkeypatch):
+    """Case 1 of the same fixture reseeds seven clusters in EVERY one of the 30 iterations: the pre-drawn pool runs dry
+    several times, the library stops without committing the iteration, the host draws more and resumes. Its inputs are
+    exact duplicates, so every assignment is an exact tie between duplicate centres -- which the reference resolves
+    by the rounding noise of torch.cdist's sgemm form (203 reseeds in the fixture, an order nothing else reproduces:
+    DESIGN.md section 2). The yardstick here is therefore the oracle with DIRECT distances (exact ties stay exact, first
+    centre wins -- the HIP kernels' arithmetic): same iteration count, number of draws and generator position, through
+    at least three refills of the pool, and the same PARTITION of the rows. (Labels may differ: a cluster mean of n
+    identical rows is the row only up to the rounding of the n-term sum, whose order differs between torch and the
+    kernel, and that last bit decides which of two duplicate centres is nearer.)"""
+    from cogstream_amd import kmeans as km
+    from cogstream_amd import ops
+    from oracle import kmeans as ok
+    g = _load("kmeans_reseed.npz")
+    feats, ts, K, seed = torch.from_numpy(g["c1_features"]), torch.from_numpy(g["c1_ts"]), int(g["c1_K"]), int(g["c1_seed"])
+    random.seed(seed)
+    torch.manual_seed(seed)
+    want_cf, want_ct, want_assign = ok.kmeans_with_time_min_max(feats, ts, K, exact_distances=True)
+    want_next = random.random()
+    calls = []
+    real = ops.kmeans_lloyd
+    monkeypatch.setattr(ops, "kmeans_lloyd", lambda *a: calls.append(real(*a)) or calls[-1])
+    random.seed(seed)
+    torch.manual_seed(seed)
+    cf, ct, assign = km.kmeans_with_time_min_max(feats.to(dev), ts, K)
+    assert random.random() == want_next
+    a, b = assign.cpu(), want_assign
+    assert torch.equal(a[:, None] == a[None, :], b[:, None] == b[None, :])            # the same partition
+    assert torch.equal(torch.bincount(a, minlength=K).sort().values, torch.bincount(b, minlength=K).sort().values)
+    for lab in a.unique().tolist():                                                    # each cluster's centre is its rows' value
+        rows = feats[a == lab].reshape(-1, cf[0].numel())
+        assert rel_err(cf[lab].reshape(-1).cpu(), rows[0]) < 1e-5
+    assert km.last_stats["iterations"] == 30 == sum(c[0] for c in calls)
+    assert sum(1 for c in calls if c[2]) >= 3 and sum(c[1] for c in calls) == 210       # 30 iterations x 7 empty clusters
+
+
 def _tiny_model(dev, dtype, attn_mode):
     from cogstream_amd.chat import CogReasoner
     from cogstream_amd.llm import Qwen2Engine

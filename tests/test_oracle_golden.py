@@ -74,6 +74,21 @@ def test_kmeans_oracle_matches_reference(ci):
         assert assign is None
 
 
+@pytest.mark.parametrize("ci", [0, 1])
+def test_kmeans_oracle_reseed_branch_matches_reference(ci):
+    """tests/golden/kmeans_reseed.npz: the reference on degenerate inputs whose duplicate centres leave clusters empty
+    (3 reseeds once / 7 reseeds in each of 30 iterations) -- assignments, centres and the generator position after the call"""
+    import random
+    from oracle import kmeans as ok
+    g = _load("kmeans_reseed.npz")
+    random.seed(int(g[f"c{ci}_seed"]))
+    torch.manual_seed(int(g[f"c{ci}_seed"]))
+    cf, ct, assign = ok.kmeans_with_time_min_max(torch.from_numpy(g[f"c{ci}_features"]), torch.from_numpy(g[f"c{ci}_ts"]), int(g[f"c{ci}_K"]))
+    assert random.random() == float(g[f"c{ci}_next_random"])
+    assert torch.equal(assign, torch.from_numpy(g[f"c{ci}_assign"]))
+    assert rel_err(cf, torch.from_numpy(g[f"c{ci}_centres"])) < 1e-5 and rel_err(ct + 1, torch.from_numpy(g[f"c{ci}_centre_ts"]) + 1) < 1e-6
+
+
 def test_compress_oracle_matches_reference():
     from oracle import compress as oc
     g = _load("compress.npz")
