@@ -36,6 +36,9 @@ struct VitAttnArgs {
     long ldq, ldk, ldv, ldo;   // elements
     const int* cu;             // [nseg + 1]
     int nseg, heads, nqb;      // grid = nseg * heads * nqb workgroups (nqb = 128-row query blocks of the longest segment)
+    int uniform_len;           // > 0: every segment has this many rows and segment s starts at row s * uniform_len (one video:
+                               // all frames alike) -- the bounds are then arithmetic on kernel arguments instead of two
+                               // dependent scalar loads at the head of every workgroup (700-1 700 cycles of its 39 000)
 };
 
 constexpr float RESCALE_THR = 6.0f;
@@ -419,7 +422,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             qb = id % p.nqb; head = (id / p.nqb) % p.heads; seg = id / (p.nqb * p.heads);
         }
     }
-    const int qs = p.cu[seg], qe = p.cu[seg + 1];
+    const int qs = p.uniform_len > 0 ? seg * p.uniform_len : p.cu[seg];
+    const int qe = p.uniform_len > 0 ? qs + p.uniform_len : p.cu[seg + 1];
     const int q0 = qs + qb * QB;
 #ifdef COGS_PIPE_STAMPS2
     asm volatile("" :: "s"(qs), "s"(qe));
@@ -761,6 +765,7 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo;
     p.cu = a.cu_seqlens;
     p.nseg = a.nseg; p.heads = a.hq; p.nqb = (a.max_seqlen + 127) / 128;
+    p.uniform_len = (a.uniform_seqlen > 0 && (long)a.uniform_seqlen * a.nseg == a.q_len && a.uniform_seqlen == a.max_seqlen) ? a.uniform_seqlen : 0;
     if ((long)p.nseg * p.heads * p.nqb > 0x7fffffffL) return COGS_E_INVALID;
     dim3 grid(p.nseg * p.heads * p.nqb);
     static const int variant = getenv("COGS_ATTN_VIT") ? atoi(getenv("COGS_ATTN_VIT")) : 2;     // 1: unpipelined (A/B runs)

@@ -519,7 +519,13 @@ static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* p
 
     // cu_seqlens (:439-440), same-frame ranges for the eager-global mode, rotary tables (:405-434): all written by
     // kernels on `st` from the grid -- no host staging, so back-to-back encodes with different grids cannot race
-    int max_seq = 0;
+    int max_seq = 0, uniform_seq = 0;
+    {
+        bool alike = true;
+        for (int v = 1; v < V; ++v)
+            alike = alike && grid_sizes[3 * v + 1] * grid_sizes[3 * v + 2] == grid_sizes[1] * grid_sizes[2];
+        if (alike) uniform_seq = (int)(grid_sizes[1] * grid_sizes[2]);
+    }
     {
         int64_t row = 0;
         int frame0 = 0;
@@ -576,7 +582,10 @@ static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* p
             a.q_len = (int)N; a.kv_len = (int)N; a.hq = a.hkv = w.heads; a.head_dim = hd; a.scale = scale;
             a.q_prescaled = prescale_q;
             if (attn_mode == COGS_ATTN_REF_EAGER_GLOBAL) { a.row_lo = lo; a.row_hi = hi; a.bias = 1.0f; }
-            else { a.cu_seqlens = cu; a.nseg = nframes; a.max_seqlen = max_seq; }
+            else {
+                a.cu_seqlens = cu; a.nseg = nframes; a.max_seqlen = max_seq;
+                a.uniform_seqlen = uniform_seq;      // all frames alike (one video, or videos of one grid): see attn_vit.hip
+            }
             { PROF(COGS_PROF_ATTN); COGS_TRY(cogs_k_attention(st, a)); }
         }
         {

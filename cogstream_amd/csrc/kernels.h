@@ -70,6 +70,7 @@ struct CogsAttn {
     void* ws = nullptr;               // nsplit*q_len*hq*(head_dim+2) floats
     size_t ws_bytes = 0;
     int q_prescaled = 0;              // Q already multiplied by scale*log2(e) (bf16 MFMA kernels only; no bias mode)
+    int uniform_seqlen = 0;           // internal hint: > 0 = every cu_seqlens segment has exactly this many rows, in order
 };
 int cogs_k_attention_vit(hipStream_t st, const struct CogsAttn& a);   // attn_vit.hip: block-diagonal, hd 72, pre-scaled Q
 int cogs_k_attention_decode(hipStream_t st, const struct CogsAttn& a, float* part_o, float* part_ml);   // attn_decode.hip: one query row, hd 128, key-split partials
