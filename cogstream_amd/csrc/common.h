@@ -102,10 +102,29 @@ template <> __device__ __forceinline__ void st8_f<float>(float* p, const float (
     *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
+// value of lane (i ^ X) for X in {8, 4, 2, 1}, by DPP (data-parallel primitives: a few cycles, no LDS). hipcc compiles
+// __shfl_xor to ds_bpermute_b32 -- an LDS-crossbar round trip of ~100 cycles per step, four DEPENDENT ones at the end of
+// every wave reduction (rocprofv3 / disassembly, round 3). Within a 16-lane row: xor 8 = rotate by 8; xor 4 = rotate by
+// 12 for the lanes with bit 2 clear (banks 0 and 2) and by 4 for the others (banks 1 and 3); xor 2 / xor 1 = quad
+// permutations. Same lanes paired in the same order as before: results are bit-identical.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, 0xf, BANKS, false));
+}
+template <int X>
+__device__ __forceinline__ float lane_xor_dpp(float v) {
+    static_assert(X == 8 || X == 4 || X == 2 || X == 1, "within a 16-lane row");
+    if constexpr (X == 8) return dpp_take<0x128, 0xf>(v, v);                       // row_ror:8
+    else if constexpr (X == 4) return dpp_take<0x124, 0xa>(dpp_take<0x12C, 0x5>(v, v), v);   // row_ror:12 | row_ror:4
+    else if constexpr (X == 2) return dpp_take<0x4E, 0xf>(v, v);                   // quad_perm [2,3,0,1]
+    else return dpp_take<0xB1, 0xf>(v, v);                                         // quad_perm [1,0,3,2]
+}
+
 // 64-lane butterfly reductions (fixed order -> deterministic). The xor-32 and xor-16 exchanges go through
 // v_permlane32_swap / v_permlane16_swap (both operands = v: afterwards the two results hold "mine" and "partner's" in
-// some order, and the operation is commutative) instead of the ds_bpermute round trips __shfl_xor compiles to;
-// xor 8..1 stay __shfl_xor (DPP). Same values, bit for bit.
+// some order, and the operation is commutative), xor 8..1 through DPP (above). Same values, bit for bit, as the
+// __shfl_xor butterfly they replace.
 template <typename F>
 __device__ __forceinline__ float wave_butterfly(float v, F op) {
     {
@@ -118,8 +137,10 @@ __device__ __forceinline__ float wave_butterfly(float v, F op) {
         const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
         v = op(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o, 64));
+    v = op(v, lane_xor_dpp<8>(v));
+    v = op(v, lane_xor_dpp<4>(v));
+    v = op(v, lane_xor_dpp<2>(v));
+    v = op(v, lane_xor_dpp<1>(v));
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
