@@ -630,6 +630,10 @@ int cogs_k_kmeans_lloyd(hipStream_t st, int dtype, const void* feats, const floa
         if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) return COGS_E_HIP;
         status_h = (volatile int*)hp; status_d = (int*)dp; status_dev = dev;
     }
+    if (iterations) *iterations = 0;
+    if (reseeds_used) *reseeds_used = 0;
+    if (exhausted) *exhausted = 0;
+    if (max_iter == 0) return COGS_OK;             // nothing to do (and nothing queued that would still read pool_host)
     const KmWs w = carve(ws, T, PD, K);
     if (hipMemsetAsync(w.ctl, 0, 16, st) != hipSuccess) return COGS_E_HIP;
     if (pool_len > 0 && hipMemcpyAsync(w.pool, pool_host, (size_t)pool_len * 4, hipMemcpyHostToDevice, st) != hipSuccess) return COGS_E_HIP;
