@@ -496,8 +496,13 @@ def test_ln_fold_with_outlier_channels_and_large_row_means(dev, kind):
         assert enc.packed.fold_ln is fold
         tok = enc(pix.to(dev, torch.bfloat16), grid, merge)
         assert bool(torch.isfinite(tok.float()).all())
-        d = (tok.float().cpu() - ref).double()
-        errs[fold] = (float(d.abs().max() / ref.abs().max()), float(d.pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt()))
+        # judged on the ORDINARY channels: the planted ones are 300 x larger, and their own bf16 rounding would be all
+        # that a max-norm or an RMS over every channel sees
+        keep = torch.ones(ref.shape[1], dtype=torch.bool)
+        if kind == "outlier_channels":
+            keep[hot] = False
+        r_, d = ref[:, keep].double(), (tok.float().cpu() - ref)[:, keep].double()
+        errs[fold] = (float(d.abs().max() / r_.abs().max()), float(d.pow(2).mean().sqrt() / r_.pow(2).mean().sqrt()))
     print(f"{kind}: folded max {errs[True][0]:.2e} rms {errs[True][1]:.2e} | unfused max {errs[False][0]:.2e} rms {errs[False][1]:.2e}")
     assert errs[True][0] <= 1.5 * errs[False][0] + 1e-3 and errs[True][1] <= 1.5 * errs[False][1] + 1e-4
     # (large_mean: rows of 12 +- 0.4 stored in bf16 carry a quantisation noise of 15 % of their spread -- BOTH paths, and the
@@ -527,6 +532,51 @@ def test_real_dimension_llm_layer_vs_oracle(dev):
     for i in range(1100, 1103):
         r = eng.forward(emb[i:i + 1].to(dev, torch.bfloat16), cache)
         assert rel_err(r["logits"], oq.logits(st, hid[i])) < 3e-2
+
+
+def test_production_depth_qwen2_28_layers_vs_oracle(dev):
+    """All 28 decoder layers at the Qwen2-7B width (hidden 3584, 28 query / 4 kv heads of 128, MLP 18944; a 4 096-entry
+    vocabulary keeps the host copy of the weights at 26 GB) against the reference-pinned oracle on a 96-token prompt and
+    two cached decode steps: the fp32 parity mode within 1e-4 through all 28 layers, the bf16 production path as close
+    to the fp32 oracle as the oracle's own bf16 run is (x 1.5; the reference runs the model in bf16 on a GPU,
+    evaluate/answer_generate.py:176). Weights are drawn on the GPU and copied to the host for the oracle."""
+    from cogstream_amd.llm import Qwen2Engine
+    from cogstream_amd.weights import LlmConfig, random_llm_state
+    from oracle import qwen2 as oq
+    from test_gpu_golden import _as_good_as_reference_bf16
+    cfg = LlmConfig(vocab_size=4096, image_token_index=4000, eos_token_id=4001)
+    assert (cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+            cfg.num_key_value_heads) == (3584, 18944, 28, 28, 4)
+    st = random_llm_state(cfg, seed=41, device=dev, dtype=torch.float32, std=0.02)
+    host = {k: v.cpu() for k, v in st.items()}
+    kw = dict(heads=28, kv_heads=4, layers=28)
+    torch.manual_seed(43)
+    S = 96
+    emb = (torch.randn(S + 2, cfg.hidden_size) * 0.5).bfloat16().float()         # bf16-representable: same input everywhere
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    hid, _ = oq.forward(host, emb, **kw)
+    want = torch.stack([oq.logits(host, hid[i]) for i in (S - 1, S, S + 1)])
+    host16 = {k: v.bfloat16() for k, v in host.items()}
+    hid16, _ = oq.forward(host16, emb.bfloat16(), **kw)
+    want16 = torch.stack([oq.logits(host16, hid16[i]).float() for i in (S - 1, S, S + 1)])
+    del host16
+
+    def run(dtype):
+        eng = Qwen2Engine(st, cfg, dtype=dtype, device=dev)
+        cache = eng.new_cache(S + 8)
+        out = [eng.forward(emb[:S].to(dev, dtype), cache)["logits"].clone()]
+        for i in (S, S + 1):
+            out.append(eng.forward(emb[i:i + 1].to(dev, dtype), cache)["logits"].clone())
+        del eng
+        torch.cuda.empty_cache()
+        return torch.stack(out).cpu()
+
+    got32 = run(torch.float32)
+    e32 = rel_err(got32, want)
+    print(f"28 layers, fp32 parity mode vs fp32 oracle (prefill + 2 decode steps): {e32:.2e}")
+    assert e32 < 1e-4
+    got16 = run(torch.bfloat16)
+    _as_good_as_reference_bf16(got16.float(), want16, want, "28-layer Qwen2 logits (prefill + 2 decode steps)")
 
 
 def test_ragged_frame_shards_equal_whole_clip_bit_for_bit(dev):
