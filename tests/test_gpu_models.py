@@ -54,6 +54,45 @@ def test_vit_bf16_pixel_input_and_frame_independence(dev):
     assert torch.equal(a[:4], b[:4]) and torch.equal(a[8:], b[8:]) and not torch.equal(a[4:8], b[4:8])
 
 
+def test_frame_split_two_stream_encode_is_transparent(dev):
+    """cogs_vit_encode cuts a small clip at the frame boundary nearest to half its patches and encodes the halves on two
+    streams (frames are independent in block-diagonal mode). Three videos of different grids in ONE call -- the cut falls
+    inside the second one, the halves see different video lists, the attention's uniform-segment shortcut is off -- must
+    equal (bit for bit) the concatenation of one encode per video, and the oracle within bf16 tolerance; a workspace too
+    small for two halves falls back to one stream instead of failing; back-to-back calls on one handle do not race."""
+    import ctypes as C
+    from cogstream_amd import _lib as L
+    from oracle import vision as ov
+    cfg, st, enc = _vit(dev, torch.bfloat16, 0)
+    torch.manual_seed(61)
+    grids = torch.tensor([[3, 8, 12], [5, 6, 10], [2, 4, 6]])
+    merges = torch.tensor([2, 2, 2])
+    rows = [int(t * a * b) for t, a, b in grids.tolist()]
+    pix = (torch.rand(sum(rows), 588) * 2 - 1).bfloat16().to(dev)
+    whole = enc(pix, grids, merges)
+    parts, r0 = [], 0
+    for v in range(3):
+        parts.append(enc(pix[r0:r0 + rows[v]], grids[v:v + 1], merges[v:v + 1]))
+        r0 += rows[v]
+    assert torch.equal(whole, torch.cat(parts))
+    again = enc(pix, grids, merges)
+    assert torch.equal(whole, again)
+    ref = ov.encode(st, pix.float().cpu(), grids, merges, heads=cfg.num_attention_heads, layers=cfg.num_hidden_layers, mode=0)
+    assert rel_err(whole.float(), ref) < 3e-2
+    # exactly the single-stream workspace (the query adds room for the second set of tables): still fine, same tokens
+    need = C.c_size_t()
+    n = sum(rows)
+    L.check(L.lib.cogs_vit_workspace_bytes(enc.handle.h, n, C.byref(need)))
+    ws = torch.empty(need.value - 64 * 1024, dtype=torch.uint8, device=dev)
+    out = torch.empty_like(whole)
+    gs = (C.c_int64 * 9)(*[int(x) for x in grids.reshape(-1).tolist()])
+    ms = (C.c_int64 * 3)(2, 2, 2)
+    rc = L.lib.cogs_vit_encode(enc.handle.h, L.current_stream(), pix.data_ptr(), L.dtype_code(pix.dtype), gs, ms, 3, 0,
+                               out.data_ptr(), ws.data_ptr(), ws.numel())
+    torch.cuda.synchronize()
+    assert rc == L.OK and torch.equal(out, whole)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
 def test_projector_vs_oracle(dev, dtype, tol):
     from cogstream_amd.vision import Projector
