@@ -99,10 +99,15 @@ def zero_sum_rows(wf: torch.Tensor) -> torch.Tensor:
     levels = torch.arange(e_lo, e_hi + 1, device=w.device, dtype=torch.float64)
     counts = torch.stack([((expo == lv) & live).sum(dim=1) for lv in levels.tolist()], dim=1)       # [rows, levels]
     start = levels[counts.argmax(dim=1)]                                                              # [rows]
+    start_max = float(start.max().item())
     for lv in reversed(levels.tolist()):
+        if lv > start_max:
+            continue
         step = 2.0 ** (lv - 7)                      # bf16: 8 significant bits
-        cand = (expo == lv) & live & (start >= lv)[:, None]
         want = torch.floor(s.abs() / step)
+        if not bool((want > 0).any()):               # no row has a whole step of this binade left to shed
+            continue
+        cand = (expo == lv) & live & (start >= lv)[:, None]
         rank = torch.cumsum(cand.to(torch.int32), dim=1)
         take = cand & (rank.double() <= want[:, None])
         delta = -torch.sign(s)[:, None] * step * take.double()
