@@ -841,7 +841,7 @@ if __name__ == "__main__":
     if "--only-preprocess" in sys.argv:
         golden_preprocess()
         sys.exit(0)
-    which = sys.argv[1:] or ["preprocess", "vit", "vit_bf16", "kmeans", "compress", "text", "e2e", "qwen2"]
+    which = sys.argv[1:] or ["preprocess", "vit", "vit_bf16", "kmeans", "kmeans_reseed", "compress", "text", "e2e", "qwen2", "lora"]
     with torch.no_grad():
         for w in which:
             globals()["golden_" + w]()
