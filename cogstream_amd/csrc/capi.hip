@@ -284,6 +284,11 @@ cogs_status cogs_kmeans_update(cogs_stream stream, int dtype, const void* feats,
     return cogs_k_kmeans_update((hipStream_t)stream, dtype, feats, ts, T, PD, K, assign, reseed_rows, centres,
                                 centre_ts, (float*)ws, cogs_k_kmeans_update_blocks(PD), shift_out);
 }
+cogs_status cogs_select_near_centroid(cogs_stream stream, const float* dist2, const int64_t* assign, int T, int K, int n_extra,
+                                      int64_t* out_idx, int32_t* out_counts) {
+    if (!dist2 || !assign || !out_idx || !out_counts) return COGS_E_INVALID;
+    return cogs_k_select_near((hipStream_t)stream, dist2, assign, T, K, n_extra, out_idx, out_counts);
+}
 cogs_status cogs_kmeans_pp_step(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD, int row, int first,
                                 float* nearest2, float* probs_host, void* ws, size_t ws_bytes) {
     int ns = 0;

@@ -130,6 +130,8 @@ int cogs_k_kmeans_update(hipStream_t st, int dtype, const void* feats, const flo
                          const int64_t* assign, const int* reseed_rows, float* centres, float* centre_ts,
                          float* ws, int nblk, float* shift_out);
 int cogs_k_kmeans_update_blocks(long PD);
+int cogs_k_select_near(hipStream_t st, const float* dist2, const int64_t* assign, int T, int K, int n, int64_t* picks,
+                       int* counts);
 
 // LLM helpers
 // append S rows of K and V (adjacent column blocks of the fused qkv buffer) to the two caches in one launch

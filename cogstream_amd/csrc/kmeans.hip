@@ -464,7 +464,75 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ d
     atomicAdd(&counts[bk], 1);
 }
 
+// select_additional_frames (model/cogreasoner_chat.py:50-64): per cluster, all members if there are at most n, else the n
+// members nearest to the centroid (smallest dist2, ties to the lower row; torch.topk(largest=False) order = ascending
+// distance). One wave per cluster; picks [K][n] int64 (-1 padded), counts [K] int32. n <= 8.
+__global__ __launch_bounds__(64) void select_near_kernel(const float* __restrict__ dist2, const int64_t* __restrict__ assign,
+                                                         int Tn, int K, int n, int64_t* __restrict__ picks,
+                                                         int* __restrict__ counts) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    // the lane's own candidates: its n best (distance, row) pairs, ascending
+    float bd[8];
+    int bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bd[j] = INFINITY; bi[j] = 0x7fffffff; }
+    int cnt = 0;
+    for (int t = lane; t < Tn; t += 64) {
+        if ((int)assign[t] != k) continue;
+        ++cnt;
+        float d = dist2[(long)t * K + k];
+        int id = t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {              // insertion into the sorted list (rows arrive in ascending order per lane)
+            if (j < n && (d < bd[j] || (d == bd[j] && id < bi[j]))) {
+                const float td = bd[j]; const int ti = bi[j];
+                bd[j] = d; bi[j] = id; d = td; id = ti;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) counts[k] = cnt < n ? cnt : n;
+    if (cnt <= n) {
+        // all members, ascending row: rank of each member = members before it
+        if (lane == 0)
+            for (int j = cnt; j < n; ++j) picks[(long)k * n + j] = -1;        // the unused slots (never written below)
+        for (int base = 0, rank = 0; base < Tn; base += 64) {
+            const int t = base + lane;
+            const bool mine = t < Tn && (int)assign[t] == k;
+            const unsigned long long m = __ballot(mine);
+            if (mine) picks[(long)k * n + rank + __popcll(m & ((1ull << lane) - 1ull))] = t;
+            rank += __popcll(m);
+        }
+        return;
+    }
+    // n rounds: the wave's best head-of-list wins and is popped from its lane
+    for (int r = 0; r < n; ++r) {
+        float d = bd[0];
+        int id = bi[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od = __shfl_xor(d, o, 64);
+            const int oi = __shfl_xor(id, o, 64);
+            if (od < d || (od == d && oi < id)) { d = od; id = oi; }
+        }
+        if (lane == 0) picks[(long)k * n + r] = id;
+        if (bi[0] == id) {                          // pop (rows are unique: exactly one lane holds the winner)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { bd[j] = bd[j + 1]; bi[j] = bi[j + 1]; }
+            bd[7] = INFINITY; bi[7] = 0x7fffffff;
+        }
+    }
+}
+
 }  // namespace
+
+int cogs_k_select_near(hipStream_t st, const float* dist2, const int64_t* assign, int T, int K, int n, int64_t* picks,
+                       int* counts) {
+    if (T <= 0 || K <= 0 || n <= 0 || n > 8) return COGS_E_INVALID;
+    hipLaunchKernelGGL(select_near_kernel, dim3(K), dim3(64), 0, st, dist2, assign, T, K, n, picks, counts);
+    return COGS_LAUNCH_CHECK();
+}
 
 // ---- workspace: [A] max(sqdist slice partials [ns][T][K], update shift partials [nblk][K]) floats, then the member
 // lists (offs [K+1], members [T]), the update scratch [2K], and the Lloyd loop's own state: dist2 [T][K] floats,

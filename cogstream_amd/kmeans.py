@@ -89,21 +89,26 @@ def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int
 
 def select_additional_frames(cls_feature: torch.Tensor, long_memory: torch.Tensor,
                              cluster_assignments: torch.Tensor, additional_frame_num: int) -> List[torch.Tensor]:
-    """per cluster: all members if <= n, else the n members nearest (L2 over P*D) to the centroid"""
+    """per cluster: all members if <= n, else the n members nearest (L2 over P*D) to the centroid. Distances and the
+    picks are computed on the device (cogs_kmeans_sqdist + cogs_select_near_centroid); only the K counts cross."""
     T = cls_feature.shape[0]
     K = long_memory.shape[0]
     dev = cls_feature.device
     x = cls_feature.reshape(T, -1).contiguous()
     c = long_memory.reshape(K, -1).to(torch.float32).contiguous()
     ws = ops.kmeans_workspace(T, x.shape[1], K, dev)
-    d2 = ops.kmeans_sqdist(x, c, None, K, ws).cpu()
-    assign = cluster_assignments.cpu()
-    out = []
-    for i in range(K):
-        members = torch.nonzero(assign == i, as_tuple=True)[0]
-        if members.numel() <= additional_frame_num:
-            out.append(members.to(dev))
-        else:
-            _, top = torch.topk(d2[members, i], k=additional_frame_num, largest=False)
-            out.append(members[top].to(dev))
-    return out
+    d2 = ops.kmeans_sqdist(x, c, None, K, ws)
+    assign = cluster_assignments.to(dev, torch.int64).contiguous()
+    if additional_frame_num > 8:                       # beyond the kernel's per-lane list: host fallback of round 1
+        d2h, ah = d2.cpu(), assign.cpu()
+        out = []
+        for i in range(K):
+            members = torch.nonzero(ah == i, as_tuple=True)[0]
+            if members.numel() <= additional_frame_num:
+                out.append(members.to(dev))
+            else:
+                _, top = torch.topk(d2h[members, i], k=additional_frame_num, largest=False)
+                out.append(members[top].to(dev))
+        return out
+    picks, counts = ops.select_near_centroid(d2, assign, additional_frame_num)
+    return [picks[i, :n] for i, n in enumerate(counts.tolist())]

@@ -213,6 +213,18 @@ def kmeans_update(feats, ts, assign, reseed_rows, centres, centre_ts, ws) -> tor
     return shift
 
 
+def select_near_centroid(dist2: torch.Tensor, assign: torch.Tensor, n: int):
+    """cogs_select_near_centroid -> (picks int64 [K, n] (-1 padded), counts int32 [K]) on the device"""
+    _need_cuda(dist2, assign)
+    T, K = dist2.shape
+    assert assign.dtype == torch.int64 and assign.numel() == T and dist2.dtype == torch.float32 and dist2.is_contiguous()
+    picks = torch.empty(K, n, device=dist2.device, dtype=torch.int64)
+    counts = torch.empty(K, device=dist2.device, dtype=torch.int32)
+    check(L.lib.cogs_select_near_centroid(current_stream(), ptr(dist2), ptr(assign), T, K, int(n), ptr(picks), ptr(counts)),
+          "cogs_select_near_centroid")
+    return picks, counts
+
+
 def kmeans_pp_step(feats, row: int, first: bool, nearest2: torch.Tensor, probs_host: Optional[torch.Tensor], ws) -> None:
     """cogs_kmeans_pp_step: nearest2 (device fp32 [T]) <- min(nearest2, |x - x[row]|^2); with probs_host (pinned CPU fp32
     [T]) the result is copied there and the stream synchronised"""

@@ -198,6 +198,13 @@ cogs_status cogs_kmeans_assign(cogs_stream stream, const float* dist2, const flo
 cogs_status cogs_kmeans_update(cogs_stream stream, int dtype, const void* feats, const float* ts, int T,
                                int64_t PD, int K, const int64_t* assign, const int32_t* reseed_rows,
                                float* centres, float* centre_ts, float* shift_out, void* ws, size_t ws_bytes);
+/* select_additional_frames (model/cogreasoner_chat.py:50-64): per cluster k, the rows the event selection always keeps --
+ * all members if there are at most n_extra (ascending row), else the n_extra members nearest to the centroid
+ * (torch.cdist + topk(largest=False): ascending distance; equal distances -> lower row first). dist2 [T][K] fp32 as
+ * cogs_kmeans_sqdist leaves it (squared distances order like distances), assign int64 [T]; out_idx int64 [K][n_extra]
+ * (-1 padded), out_counts int32 [K] = min(members, n_extra). n_extra <= 8. */
+cogs_status cogs_select_near_centroid(cogs_stream stream, const float* dist2, const int64_t* assign, int T, int K, int n_extra,
+                                      int64_t* out_idx, int32_t* out_counts);
 /* One k-means++ step (:46-60): squared distance of every row to feature row `row`, folded into nearest2 (device fp32 [T]:
  * first != 0 stores, else min). probs_host (pinned host fp32 [T], nullable): the updated nearest2 is copied there and the
  * stream is synchronised, so the caller can draw the next centre (torch.multinomial on the CPU generator) right away.

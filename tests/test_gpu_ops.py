@@ -661,6 +661,34 @@ def test_ln_fold_through_the_c_abi_as_the_header_states_it(dev):
     assert L.lib.cogs_gemm(L.current_stream(), C.byref(d)) == L.E_UNSUPPORTED        # row_stats + GELU(erf): no such epilogue
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+def test_select_near_centroid_vs_torch(dev, n):
+    """cogs_select_near_centroid against the reference's per-cluster logic (model/cogreasoner_chat.py:50-64: members if at
+    most n, else members[topk(dist, n, largest=False)]) on random distances: clusters with 0, fewer than n, exactly n and
+    many members; T beyond one 64-row sweep; exact ties go to the lower row."""
+    ops = _ops()
+    torch.manual_seed(70 + n)
+    T, K = 333, 11
+    d2 = torch.rand(T, K)
+    d2[5::40] = d2[6::40][: d2[5::40].shape[0]]                                # some exactly equal rows (ties)
+    assign = torch.randint(0, K - 3, (T,))
+    assign[:2] = K - 3                                                        # a cluster with 2 members
+    assign[2:2 + n] = K - 2                                                   # a cluster with exactly n members (cluster K-1: none)
+    picks, counts = ops.select_near_centroid(d2.to(dev), assign.to(dev), n)
+    picks, counts = picks.cpu(), counts.cpu()
+    for k in range(K):
+        members = torch.nonzero(assign == k, as_tuple=True)[0]
+        if members.numel() <= n:
+            want = members
+        else:
+            dk = d2[members, k]
+            order = sorted(range(members.numel()), key=lambda i: (float(dk[i]), int(members[i])))[:n]
+            want = members[torch.tensor(order)]
+        assert int(counts[k]) == want.numel()
+        assert picks[k, :want.numel()].tolist() == want.tolist()
+        assert (picks[k, want.numel():] == -1).all()
+
+
 def L_ACT_NONE():
     from cogstream_amd import _lib as L
     return L.ACT_NONE
