@@ -82,7 +82,7 @@ def hbm_stage(name, kernel, ref, nbytes, seconds, note):
             "frac": round(tbps / HBM_PEAK_TBPS, 4), "note": note}
 
 
-def stage_rooflines(c3, mm3, dev):
+def stage_rooflines(c3, mm3, dev, with_cpu=True):
     """The HBM-bound stages of the path at BASELINE configs[2] size (256 frames, 50 tokens per frame), each timed as
     the product calls it (host control included -- k-means keeps the reference's host RNG draws):
     k-means (A8), pixel-difference mask (A12), compaction + embedding splice (A13-A14)."""
@@ -142,6 +142,30 @@ def stage_rooflines(c3, mm3, dev):
     out.append(hbm_stage("_compress_visual_tokens + prepare_inputs_labels_for_multimodal (A13-A14)",
                          "gather_rows_kernel (csrc/compress.hip)", "model/cogreasoner_chat.py:449-476,567-572",
                          2 * S * D * es, t_g, f"{S} prompt rows of {D} bf16 read + written once; 50 calls back to back per sample"))
+    if with_cpu:
+        # the CPU restatement (oracle/, torch fp32 on this box's host cores) of the same stages on the same inputs, once each
+        from oracle import compress as oc
+        from oracle import kmeans as ok
+        ncpu = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        torch.set_num_threads(ncpu)
+        f_cpu = feats.float().cpu()
+        random.seed(0)
+        torch.manual_seed(0)
+        t0 = time.perf_counter()
+        ok.kmeans_with_time_min_max(f_cpu, tsd, K)
+        t_km_cpu = time.perf_counter() - t0
+        p_cpu = pix3.float().cpu()
+        grid3 = torch.tensor([[T3, gh3, gw3]])
+        t0 = time.perf_counter()
+        oc.compression_mask(p_cpu, grid3, torch.tensor([2]), ["video"], minor_frame_indices=[])
+        t_pd_cpu = time.perf_counter() - t0
+        tab_cpu, mm_cpu, idx_cpu = table.float().cpu(), mm3.float().cpu(), idx.cpu()
+        t0 = time.perf_counter()
+        torch.where((idx_cpu >= 0)[:, None], tab_cpu[idx_cpu.clamp_min(0)], mm_cpu[(-idx_cpu - 1).clamp_min(0)])
+        t_g_cpu = time.perf_counter() - t0
+        for st_, tc in zip(out, (t_km_cpu, t_pd_cpu, t_g_cpu)):
+            st_["cpu_baseline"] = {"ms": round(tc * 1e3, 2), "cores": ncpu, "kind": "port",
+                                   "speedup": round(tc / (st_["ms"] * 1e-3), 1)}
     return out
 
 
@@ -388,7 +412,7 @@ def main() -> None:
             if world == 1 and R > 1 and 256 % R == 0:
                 out["cfg3"]["shard%d" % R] = shard_probe(c3["pix"], 256, c3["gh"], c3["gw"], dt3 / n3 * 1e3, R)
         if rank == 0 and world == 1:
-            out["stages"] = stage_rooflines(c3, mm3, dev)
+            out["stages"] = stage_rooflines(c3, mm3, dev, with_cpu=not args.no_cpu)
         del c3, mm3
 
     # ---- Qwen2-7B: prefill of the interleaved prompt + greedy decode (rank 0; other ranks wait) ----
