@@ -455,7 +455,14 @@ def main() -> None:
                       "decode_s": round(t_dec, 4), "ms_per_token": round(t_dec / n_fwd * 1e3, 4), "prefill_tflops": round(
                           (2.0 * S * 6.526e9 + 2.0 * S * S * lcfg.hidden_size * lcfg.num_hidden_layers / 2) / t_prefill / 1e12, 1),
                       "timing": "prefill and token loop timed separately, both after a full-size warm-up"}
+        dtraffic, dsrc = None, None
+        dpath = os.path.join(ROOT, "profiles", "r3_decode_traffic.json")
+        if os.path.exists(dpath):       # fabric-side read bytes of one decode step, from a separate rocprofv3 --pmc pass
+            dtraffic = json.load(open(dpath)).get("fetch_bytes_per_token")
+            dsrc = ("committed PMC profile profiles/r3_decode_traffic.json (rocprofv3 --pmc FETCH_SIZE on tools/decode_trace.py "
+                    "at the same context, tools/decode_traffic.py; FETCH doubled per the gfx950 correction), not this run")
         out["decode"] = {"roofline": {"bound": "hbm", "bytes_per_token": int(bytes_per_token),
+                                      "traffic": dtraffic, "traffic_source": dsrc,
                                       "achieved_TBps": round(tbps, 3), "peak_TBps": HBM_PEAK_TBPS,
                                       "frac_of_8TBps": round(tbps / HBM_PEAK_TBPS, 4),
                                       "kernel": "gemv_kernel<*> weight streaming + attn_decode_kernel (csrc/gemv.hip, "
