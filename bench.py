@@ -3,26 +3,32 @@
 64-frame 480p clip, VideoLLaMA3-7B dimensions, bf16 (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+N > 1 as a plain command: the parent process -- before it touches the GPU -- starts N fresh rank processes
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`),
+relays rank 0's JSON line and exits with their status. Started under torch.distributed.run by someone else
+(RANK / WORLD_SIZE in the environment) it is simply one of the ranks.
 
 One STEP = one pass of the encoder stage over the clip with pixel_values already resident in HBM:
 cogs_vit_encode (patch-embed GEMM, 27 x {LN, QKV GEMM+RoPE, per-frame attention, out-proj, LN, MLP},
 post-LN + 2x2 merge) + cogs_project -- SURVEY.md section 8(d) "frames/sec encoded = T / t(A1..A7)".
 N > 1: the clip's frames are sharded, rank r encodes and projects its contiguous slice, ONE RCCL all-gather
 reassembles the [M,3584] visual tokens in frame order on every rank (the LLM rank needs them all); time = max
-over ranks. Default `--scaling weak`: the clip grows with N (64 frames per GPU: N = 4 is BASELINE.json's
-256-frame configs[2] clip), so per-GPU work is the N = 1 workload; `--scaling strong` shards the 64-frame clip
-itself (8 frames per GPU at N = 8). The Qwen2 section, the pre-processing line and the CPU baseline are N = 1 only.
+over ranks. The headline at EVERY N is the metric's own clip -- BASELINE configs[1], 64 frames -- so the N = 1, 2, 4, 8
+values are one STRONG-scaling curve of a fixed workload (32 / 16 / 8 frames per GPU). Side keys of the same line:
+  cfg3   BASELINE configs[2]: ONE 256-frame 480p clip (16 384-token budget -> 140x280 per frame, 200 patches / 50
+         tokens per frame), frames sharded over the N ranks (32 per GPU at N = 8), one all-gather -- strong scaling
+  weak   N > 1: the clip grows with N at 64 frames per GPU (every rank keeps the N = 1 workload; the only added cost is
+         the all-gather) -- near-linear by construction, reported for completeness
+`--config cfg3` makes configs[2] the timed headline instead; `--scaling weak` the weak curve; `--config cfg5` is
+BASELINE configs[4]: every rank answers its OWN 64-frame clip through the whole product API (processor -> qa_selection
+-> generate), replicas only, no collective.
 
-`--config cfg3` makes BASELINE.json configs[2] the timed workload instead: ONE 256-frame 480p clip (16 384-token budget
--> 140x280 per frame, 200 patches / 50 tokens per frame), its frames sharded over the N ranks (32 per GPU at N = 8),
-one all-gather -- strong scaling of a fixed clip. With the default config the same measurement rides along as the
-extra key "cfg3" at every N that divides 256 (a few untimed-region steps after the headline), so the N = 1..8 runs
-carry both curves: the headline weak-scaling one and configs[2]'s.
-
-The same JSON line also carries, measured after the timed steps on rank 0:
+The same JSON line also carries, measured after the timed steps on rank 0 at N = 1:
   answer_tokens_per_s   greedy decode rate of the Qwen2-7B path (prefill of the full ~15k-token
                         interleaved prompt, then 128 tokens, EOS ignored), e2e_s the whole answer latency;
+  pipeline              wall time of CogStreamProcessor -> qa_selection -> generate (64 new tokens) through the product
+                        API at cfg2 and cfg3 with real-tokenizer prompt lengths, split by stage;
   roofline              the dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of the encoder's GEMM
                         launches / their summed duration, measured live with HIP events on the launch stream;
   cpu_baseline          the oracle (CPU fp32 restatement of the reference) timed on this box's host cores
@@ -169,6 +175,168 @@ def stage_rooflines(c3, mm3, dev, with_cpu=True):
     return out
 
 
+class PromptLengthTokenizer:
+    """A tokenizer whose token COUNTS on this bench's prompts are the real Qwen2 tokenizer's (the vocabulary does not
+    ship: reference data). Qwen2's pre-tokenisation regex cuts the text; a pre-token is one id, except the few words of
+    the fixed prompts that the real BPE cuts further (EXTRA, read off the real tokenizer in the build container). The
+    ids are arbitrary stand-ins below the special range -- random-init weights do not care; the chat specials and
+    <image> have their real ids. Checked against the recorded real lengths: cfg2 15 395, cfg1 621, cfg3 15 295 prompt
+    tokens, event-summary prompt 974 (tests/test_tokenizer_golden.py, tests/golden/tokenizer.json)."""
+    PRETOKENIZE = (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+")
+    SPECIAL = {"<|im_start|>": 151644, "<|im_end|>": 151645, "<|endoftext|>": 151643, "<image>": 151665}
+    EXTRA = {"VideoLLaMA": 3, "DAMO": 1, "summarizing": 1, "timestamped": 1, "Concisely": 2, "adhering": 1}
+    GLUED = {"(s"}      # punctuation + letters that ARE one vocabulary entry; any other such pre-token (",Time") is two ids
+    init_kwargs = {}
+    pad_token_id = 151643
+
+    def __init__(self):
+        import regex
+        self._split = regex.compile("(" + "|".join(regex.escape(t) for t in self.SPECIAL) + ")")
+        self._pre = regex.compile(self.PRETOKENIZE)
+
+    def encode(self, text, add_special_tokens=False):
+        import zlib
+        out = []
+        for part in self._split.split(text):
+            if part in self.SPECIAL:
+                out.append(self.SPECIAL[part])
+            elif part:
+                for m in self._pre.finditer(part):
+                    w = m.group(0)
+                    h = zlib.crc32(w.encode("utf-8"))
+                    n = 1 + self.EXTRA.get(w.strip(), 0)
+                    if len(w) > 1 and not (w[0].isalpha() or w[0].isspace() or w[0].isdigit()) and w[1].isalpha() and w not in self.GLUED:
+                        n += 1
+                    out.extend((h + 7919 * i) % 151000 for i in range(n))
+        return out
+
+    def __call__(self, text, return_tensors="pt", padding=False, truncation=False, max_length=None, **kw):
+        ids = self.encode(text)
+        if truncation and max_length is not None:
+            ids = ids[:max_length]
+        t = torch.tensor([ids], dtype=torch.long)
+        return {"input_ids": t, "attention_mask": torch.ones_like(t)}
+
+    def decode(self, ids, skip_special_tokens=False):
+        return " ".join(str(int(i)) for i in ids)
+
+    def batch_decode(self, batch, skip_special_tokens=False):
+        return [self.decode(b, skip_special_tokens) for b in batch]
+
+
+QUESTION = "What is happening in the video?"
+
+
+def pipeline_once(model, processor, dframes, new_tokens, expect_prompt=None):
+    """one answer through the product API, as evaluate/answer_generate.py:60-76 drives the reference: processor ->
+    qa_selection(mode="FCC") -> generate (greedy, EOS ignored, `new_tokens` tokens). -> stage split in seconds"""
+    import random
+    random.seed(0)
+    torch.manual_seed(0)
+    T = dframes.shape[0]
+    conversation = [{"role": "user", "content": [{"type": "video", "video": dframes, "timestamps": [float(i) for i in range(T)]},
+                                                 {"type": "text", "text": QUESTION}]}]
+    model.stage_times = st = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inputs = processor(conversation=conversation, add_system_prompt=True, add_generation_prompt=True, return_tensors="pt")
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if expect_prompt is not None and int(inputs["input_ids"].shape[1]) != expect_prompt:
+        raise RuntimeError(f"prompt of {int(inputs['input_ids'].shape[1])} tokens, the real tokenizer makes {expect_prompt}")
+    inputs = model.qa_selection(**inputs, mode="FCC", select_gt=None, if_visual=None)
+    ids, _ = model.generate(**inputs, max_new_tokens=new_tokens, do_sample=False, repetition_penalty=1.05, eos_token_id=[])
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    model.stage_times = None
+    assert ids.shape == (1, new_tokens)
+    split = {"processor": t1 - t0, **{k: st.get(k, 0.0) for k in ("encode", "kmeans", "event_prefill", "answer_prefill", "decode")}}
+    split["host_and_small_kernels"] = (t2 - t0) - sum(split.values())
+    return {"total_s": round(t2 - t0, 4), "prompt_tokens": int(inputs["input_ids"].shape[1]),
+            "kept_visual_tokens": int(model.last_debug["compression_mask"].sum()),
+            "minor_frames": len(model.last_debug.get("minor_frames", [])), "event_tokens": model.last_debug.get("event_tokens", 0),
+            "new_tokens": new_tokens, "stages_s": {k: round(v, 4) for k, v in split.items()}}
+
+
+def build_model(dev, enc=None, proj=None):
+    """the full-size model on `dev`, random-init (no checkpoint is reachable), behind the product classes"""
+    from cogstream_amd import processing
+    from cogstream_amd.chat import CogReasoner
+    from cogstream_amd.llm import Qwen2Engine
+    from cogstream_amd.vision import Projector, VisionEncoder
+    from cogstream_amd.weights import LlmConfig, VisionConfig, random_llm_state, random_proj_state, random_vit_state
+    vcfg, lcfg = VisionConfig(), LlmConfig()
+    if enc is None:
+        enc = VisionEncoder(random_vit_state(vcfg, seed=0, device=dev, dtype=torch.bfloat16), vcfg, dtype=torch.bfloat16, device=dev)
+        proj = Projector(random_proj_state(vcfg.hidden_size, lcfg.hidden_size, seed=1, device=dev, dtype=torch.bfloat16),
+                         dtype=torch.bfloat16, device=dev)
+    eng = Qwen2Engine(random_llm_state(lcfg, seed=2, device=dev, dtype=torch.bfloat16), lcfg, dtype=torch.bfloat16, device=dev)
+    torch.cuda.empty_cache()
+    model = CogReasoner(enc, proj, eng, lcfg, generation_config=dict(do_sample=False, eos_token_id=[]))
+    processor = processing.CogStreamProcessor(PromptLengthTokenizer(), device=dev)
+    return model, processor, eng
+
+
+def bench_cfg5(args, rank, world, dev, ranks_seen):
+    """BASELINE configs[4]: one 64-frame 480p clip per GPU, every rank an independent replica of the whole model
+    answering its own clip through the product API -- the reference's DistributedSampler mode
+    (evaluate/answer_generate.py:186-187). Replicas only: no data-path collective; a step = one answer per rank."""
+    import torch.distributed as dist
+    from cogstream_amd import processing
+    model, processor, _ = build_model(dev)
+    fr, _ = processing.synthetic_clip(args.frames, kind=args.clip, clip_idx=rank)
+    dfr = torch.from_numpy(fr).to(dev)
+    new_tokens = min(args.decode_tokens, 64)
+    for _ in range(max(args.warmup, 1)):
+        pipeline_once(model, processor, dfr, new_tokens)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = pipeline_once(model, processor, dfr, new_tokens)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    answers = world * args.steps
+    return {"metric": "frames/sec encoded + answer tokens/sec, 64-frame clip, VideoLLaMA3-7B",
+            "value": round(answers * args.frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "ranks_seen": ranks_seen,
+            "answers_per_s": round(answers / dt, 3), "answer_tokens_per_s_end_to_end": round(answers * new_tokens / dt, 2),
+            "config": {"workload": f"cfg5 (BASELINE configs[4]): {world} concurrent {args.frames}x480x854 '{args.clip}' clips, one per GPU, each "
+                                   f"answered end to end (processor -> qa_selection -> generate, {new_tokens} new tokens, greedy); value = "
+                                   f"frames of the answered clips per second of wall time; random-init weights",
+                       "frames": args.frames * world, "frames_per_gpu": args.frames,
+                       "parallelism": "replicas only: every rank holds the whole model, no collective (evaluate/answer_generate.py:186-187)"},
+            "pipeline_rank0": rec}
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` as a plain command: start N fresh rank processes from THIS process, which has not
+    touched the GPU (importing torch initialises nothing), relay rank 0's JSON line, return the children's status.
+    Never an exec of a GPU-initialised process."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:        # rank 0 prints the one JSON line; anything else the ranks wrote to stdout goes to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,39 +346,48 @@ def main() -> None:
     ap.add_argument("--decode-tokens", type=int, default=128)
     ap.add_argument("--no-llm", action="store_true", help="skip the Qwen2 prefill/decode section")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the product-API pipeline timing")
     ap.add_argument("--clip", default="noise", choices=["noise", "drift"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = --frames per GPU (clip of frames*N), strong = --frames in total")
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"],
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1 headline: strong = --frames in total (the metric's clip at every N; default), weak = --frames "
+                         "per GPU (clip of frames*N)")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
                     help="cfg2: BASELINE configs[1] (64-frame clip; the metric's config). cfg3: configs[2], one 256-frame "
-                         "clip at the 16384-token budget (140x280 per frame) sharded over the ranks")
+                         "clip at the 16384-token budget (140x280 per frame) sharded over the ranks. cfg5: configs[4], one "
+                         "64-frame clip per GPU answered through the whole product API (replicas, no collective)")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the extra configs[2] measurement of the default run")
+    ap.add_argument("--payload", default="projected", choices=["projected", "encoder"],
+                    help="N > 1: what the all-gather carries (3584-wide projected tokens / 1152-wide encoder tokens, "
+                         "projector then runs on every rank)")
     ap.add_argument("--emulate-shard", type=int, default=8,
                     help="N = 1 only: also time ONE rank's share (1/R of the frames) of the clip on this GPU and report "
                          "shard_efficiency = (t_clip / R) / t_shard (0 = off)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     import torch.distributed as dist
 
     # rehearsal on a one-GPU box only: COGS_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo (the
-    # all-gather then stages through host memory, see parallel.gather_tokens); never set by the driver
+    # all-gather then stages through host memory, see parallel.gather_rows); never set by the driver
     rehearsal = os.environ.get("COGS_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        one = torch.ones(1, device="cpu" if rehearsal else dev)
+        dist.all_reduce(one)                 # counted through the communicator, not read from the environment
+        ranks_seen = int(one.item())
 
     from cogstream_amd import _lib as L
     from cogstream_amd import processing
@@ -221,6 +398,14 @@ def main() -> None:
     vcfg, lcfg = VisionConfig(), LlmConfig()
     from cogstream_amd.parallel import frame_shards, gather_tokens
     from cogstream_amd.preprocess_gpu import preprocess_videos_gpu
+    if args.config == "cfg5":
+        out = bench_cfg5(args, rank, world, dev, ranks_seen)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
     cfg3 = args.config == "cfg3"
     if cfg3:
         args.frames, args.scaling = 256, "strong"
@@ -270,49 +455,64 @@ def main() -> None:
     proj = Projector(random_proj_state(vcfg.hidden_size, lcfg.hidden_size, seed=1, device=dev, dtype=torch.bfloat16),
                      dtype=torch.bfloat16, device=dev)
     del vit_state
+    wide = args.payload == "projected"
+
+    def encode_step(clip, grid_full):
+        """one step on this rank's frames of `clip` + the all-gather: projected tokens [M, 3584] on every rank"""
+        tok = enc(clip["pix"], clip["grid_loc"], merge)
+        if wide or world == 1:
+            return gather_tokens(proj(tok), grid_full, 2, world)
+        return proj(gather_tokens(tok, grid_full, 2, world))
 
     def step():
-        return gather_tokens(proj(enc(pix, grid_loc, merge)), (T, gh, gw), 2, world)
+        return encode_step(main_clip, (T, gh, gw))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mm = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+    def timed(fn, warmup, steps):
+        """W untimed + exactly K timed steps between barrier + synchronise on both sides; MAX over the ranks"""
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_], device="cpu" if rehearsal else dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt)
+        return dt_, r
+
+    dt, mm = timed(step, args.warmup, args.steps)
     ms_per_step = dt / args.steps * 1e3
     fps = T * args.steps / dt
+    gather_note = (f"one RCCL all-gather of the [M,{lcfg.hidden_size}] projected tokens" if wide else
+                   f"one RCCL all-gather of the [M,{vcfg.hidden_size}] encoder tokens, projector on every rank")
 
     out = {
         "metric": "frames/sec encoded + answer tokens/sec, 64-frame clip, VideoLLaMA3-7B",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "strong" if (cfg3 or (world > 1 and not weak)) else "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak" if weak else "strong", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic", "ranks_seen": ranks_seen,
         "config": {"workload": f"{'cfg3 (BASELINE configs[2])' if cfg3 else ('cfg2 (BASELINE configs[1])' if T == 64 else 'cfg2-sized frames')}: "
                                f"{T}x480x854 '{args.clip}' clip -> {gh * 14}x{gw * 14}, "
                                f"{n_patches} patches, {m_tokens} visual tokens; ViT(1152x27, hd72)+projector(3584); "
                                f"random-init weights"
-                               + (f"; WEAK scaling over {world} GPUs (the clip grows with N at {t_loc} frames per GPU -- "
-                                  f"BASELINE configs[2]'s fixed 256-frame clip, strong scaling, is this line's 'cfg3' key)" if weak else
-                                  (f"; STRONG scaling over {world} GPUs ({t_loc} frames per GPU)" if world > 1 else "")),
-                   "scaling_note": ("WEAK scaling: the clip grows with N (64 frames per GPU); the strong-scaling curve of the "
-                                    "fixed 256-frame configs[2] clip is the 'cfg3' key of this line") if weak else
-                                   ("strong scaling of one fixed clip" if world > 1 else "single GPU"),
+                               + (f"; WEAK scaling over {world} GPUs (the clip grows with N at {t_loc} frames per GPU)" if weak else
+                                  (f"; STRONG scaling over {world} GPUs: the same fixed clip as at N = 1, {t_loc} frames per GPU" if world > 1 else "")),
+                   "scaling_note": ("WEAK scaling: the clip grows with N" if weak else
+                                    "STRONG scaling: the workload is the same fixed clip at every N (the N = 1 line is this curve's "
+                                    "first point); side keys: 'cfg3' = BASELINE configs[2]'s 256-frame clip sharded the same way, "
+                                    "'weak' = 64 frames per GPU"),
                    "frames": T, "frames_per_gpu": t_loc, "patches": n_patches, "visual_tokens": m_tokens,
-                   "parallelism": (f"frames sharded over {world} GPUs ({t_loc} each), encode+project per rank, one RCCL "
-                                   f"all-gather of the [M,3584] tokens") if world > 1 else "single GPU"},
+                   "parallelism": (f"frames sharded over {world} GPUs ({t_loc} each), encode+project per rank, {gather_note}")
+                   if world > 1 else "single GPU"},
     }
 
     # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events around every launch ----
@@ -322,7 +522,7 @@ def main() -> None:
     cnt = (C.c_int * 4)()
     barrier()
     L.check(L.lib.cogs_profile_begin(h.h))
-    gather_tokens(proj(enc(pix, grid_loc, merge)), (T, gh, gw), 2, world)
+    step()
     L.check(L.lib.cogs_profile_end(h.h, L.current_stream(), ms, cnt))
     if rank == 0:
         n_loc, m_proj = t_loc * per_frame, t_loc * P
@@ -380,40 +580,38 @@ def main() -> None:
     if rank == 0 and world == 1 and R > 1 and T % R == 0:
         out["shard%d" % R] = shard_probe(pix, T, gh, gw, ms_per_step, R)
 
-    # ---- BASELINE configs[2] riding along: one 256-frame clip at the 16384-token budget, frames sharded over the
-    # ranks (32 per GPU at N = 8), one all-gather; every rank takes part, rank 0 reports ----
-    if not cfg3 and not args.no_cfg3 and 256 % world == 0 and args.frames == 64:
-        c3 = make_clip(256, 256)
-        g3 = (256, c3["gh"], c3["gw"])
+    # ---- side curves, every rank takes part, rank 0 reports ----
+    def side_curve(T_clip, budget, label):
+        c = make_clip(T_clip, budget)
+        g = (T_clip, c["gh"], c["gw"])
+        n = max(3, min(args.steps, 10))
+        dt_, mm_ = timed(lambda: encode_step(c, g), 1, n)
+        pf = c["gh"] * c["gw"]
+        fl = vit_gemm_flops(T_clip * pf, T_clip * pf // 4, vcfg, lcfg.hidden_size) + vit_attn_flops(T_clip, pf, vcfg)
+        rec = {"workload": f"{label}: {T_clip}x480x854 '{args.clip}' clip -> {c['gh'] * 14}x{c['gw'] * 14}, {T_clip * pf} patches, "
+                           f"{T_clip * pf // 4} visual tokens, {c['t_loc']} frames per GPU" + (", one all-gather" if world > 1 else ""),
+               "value": round(T_clip * n / dt_, 2), "unit": "frames/s", "ms_per_step": round(dt_ / n * 1e3, 3), "steps": n,
+               "n_gpus": world, "frames": T_clip, "frames_per_gpu": c["t_loc"], "encoder_tflops": round(fl / (dt_ / n) / 1e12, 1)}
+        return rec, c, mm_, dt_ / n
 
-        def step3():
-            return gather_tokens(proj(enc(c3["pix"], c3["grid_loc"], merge)), g3, 2, world)
-
-        step3()
-        barrier()
-        n3 = max(3, min(args.steps, 10))
-        t0 = time.perf_counter()
-        for _ in range(n3):
-            mm3 = step3()
-        barrier()
-        dt3 = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt3], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt3 = float(tt)
-        pf3 = c3["gh"] * c3["gw"]
+    # BASELINE configs[2]: one 256-frame clip at the 16384-token budget, frames sharded over the ranks (32 per GPU at N = 8)
+    if not cfg3 and not args.no_cfg3 and args.frames == 64 and not weak:
+        rec3, c3, mm3, t3 = side_curve(256, 256, "BASELINE configs[2]")
+        rec3["scaling"] = "strong"
         if rank == 0:
-            fl3 = vit_gemm_flops(256 * pf3, 64 * pf3, vcfg, lcfg.hidden_size) + vit_attn_flops(256, pf3, vcfg)
-            out["cfg3"] = {"workload": f"BASELINE configs[2]: 256x480x854 '{args.clip}' clip -> {c3['gh'] * 14}x{c3['gw'] * 14}, "
-                                       f"{256 * pf3} patches, {64 * pf3} visual tokens, {c3['t_loc']} frames per GPU, one all-gather",
-                           "value": round(256 * n3 / dt3, 2), "unit": "frames/s", "ms_per_step": round(dt3 / n3 * 1e3, 3),
-                           "steps": n3, "scaling": "strong", "n_gpus": world, "frames_per_gpu": c3["t_loc"],
-                           "encoder_tflops": round(fl3 / (dt3 / n3) / 1e12, 1)}
+            out["cfg3"] = rec3
             if world == 1 and R > 1 and 256 % R == 0:
-                out["cfg3"]["shard%d" % R] = shard_probe(c3["pix"], 256, c3["gh"], c3["gw"], dt3 / n3 * 1e3, R)
+                out["cfg3"]["shard%d" % R] = shard_probe(c3["pix"], 256, c3["gh"], c3["gw"], t3 * 1e3, R)
         if rank == 0 and world == 1:
             out["stages"] = stage_rooflines(c3, mm3, dev, with_cpu=not args.no_cpu)
         del c3, mm3
+    # the weak curve: 64 frames per GPU (N = 4 is a 256-frame clip at cfg2's frame size)
+    if world > 1 and not cfg3 and not weak and args.frames == 64:
+        recw, cw, mmw, _ = side_curve(64 * world, 64, "cfg2-sized frames, clip grows with N")
+        recw["scaling"] = "weak"
+        if rank == 0:
+            out["weak"] = recw
+        del cw, mmw
 
     # ---- Qwen2-7B: prefill of the interleaved prompt + greedy decode (rank 0; other ranks wait) ----
     if rank == 0 and world == 1 and not args.no_llm:
@@ -481,8 +679,57 @@ def main() -> None:
         out["answer_tokens_per_s_sampled"] = round((len(toks_s) - 1) / t_dec_s, 2)
         out["llm"]["sampled"] = {"config": "do_sample T=0.7 top_k=20 top_p=0.8 repetition_penalty=1.05 (generation_config.json)",
                                  "decode_tokens": len(toks_s), "decode_s": round(t_dec_s, 4), "sampler": "device (cogs_sample, Philox)"}
-        del eng, cache
+        del cache
         torch.cuda.empty_cache()
+        # ---- the whole product path, driver-timed: CogStreamProcessor -> qa_selection -> generate (64 new tokens,
+        # greedy) with the real tokenizer's prompt lengths, at cfg2 (this clip) and cfg3 (256 frames: k-means +
+        # 18 event-summary passes); evaluate/answer_generate.py:60-76 ----
+        if not args.no_pipeline and T == 64 and not cfg3:
+            from cogstream_amd.chat import CogReasoner
+            model = CogReasoner(enc, proj, eng, lcfg, generation_config=dict(do_sample=False, eos_token_id=[]))
+            processor = processing.CogStreamProcessor(PromptLengthTokenizer(), device=dev)
+            pipeline_once(model, processor, dframes, 4)                       # warm-up
+            out["pipeline"] = {"cfg2": pipeline_once(model, processor, dframes, 64, expect_prompt=prompt_tokens(64, P)),
+                               "note": "wall time of one answer through the product API (evaluate/answer_generate.py:60-76), raw "
+                                       "uint8 frames already on the GPU; stages_s: each stage drained on both sides; "
+                                       "host_and_small_kernels = the rest (tokenisation, index bookkeeping, pixel-diff mask, "
+                                       "compaction, splice)"}
+            clip256 = torch.from_numpy(np.concatenate([processing.synthetic_clip(64, kind="drift", clip_idx=c)[0]
+                                                       for c in range(4)])).to(dev)
+            pipeline_once(model, processor, clip256, 4)
+            out["pipeline"]["cfg3"] = pipeline_once(model, processor, clip256, 64, expect_prompt=prompt_tokens(256, 50))
+            out["pipeline"]["cfg3"]["clip"] = "drift (the noise clip keeps every token; drift prunes by pixel difference)"
+            del clip256, model
+        del eng
+        torch.cuda.empty_cache()
+        # ---- CPU column for the token rate: the oracle's Qwen2 (torch fp32) decoding ONE token at the same context on
+        # the host cores -- 2 of the 28 layers timed and scaled, plus the lm_head (a bounded sample: ~10-20 s) ----
+        if not args.no_cpu:
+            from oracle import qwen2 as oq
+            ncpu = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+            torch.set_num_threads(ncpu)
+            l2 = LlmConfig(num_hidden_layers=2)
+            wc = random_llm_state(l2, seed=2, device="cpu", dtype=torch.float32)
+            kvh, hd = l2.num_key_value_heads, l2.head_dim
+            past = [(torch.randn(kvh, S, hd), torch.randn(kvh, S, hd)) for _ in range(2)]
+            e1 = torch.randn(1, l2.hidden_size) * 0.02
+            with torch.no_grad():
+                oq.forward(wc, e1, heads=l2.num_attention_heads, kv_heads=kvh, layers=2, past=past)       # warm-up
+                n_tok = 3
+                t0 = time.perf_counter()
+                for _ in range(n_tok):
+                    hid, _ = oq.forward(wc, e1, heads=l2.num_attention_heads, kv_heads=kvh, layers=2, past=past)
+                t_layers = (time.perf_counter() - t0) / n_tok
+                t0 = time.perf_counter()
+                for _ in range(n_tok):
+                    oq.logits(wc, hid[-1])
+                t_head = (time.perf_counter() - t0) / n_tok
+            t_tok = t_layers * (lcfg.num_hidden_layers / 2) + t_head
+            out["decode"]["cpu_baseline"] = {"value": round(1.0 / t_tok, 3), "unit": "tokens/s", "cores": ncpu, "kind": "port",
+                                             "sample": f"oracle.qwen2.forward (torch fp32) decoding one token at context {S}: 2 of "
+                                                       f"{lcfg.num_hidden_layers} layers timed ({t_layers * 1e3:.0f} ms) and scaled x"
+                                                       f"{lcfg.num_hidden_layers // 2}, + lm_head ({t_head * 1e3:.0f} ms); {n_tok} tokens"}
+            del wc, past
 
     # ---- GPU pre-processing of the clip (uint8 frames -> pixel_values) ----
     if rank == 0 and world == 1:

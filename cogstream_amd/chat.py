@@ -125,12 +125,35 @@ def parse_selection(selection_module_output: str):
     return if_visual, idx
 
 
+class _Stage:
+    def __init__(self, owner, name):
+        self.times, self.name = getattr(owner, "stage_times", None), name
+
+    def __enter__(self):
+        if self.times is not None:
+            import time
+            torch.cuda.synchronize()
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if self.times is not None:
+            import time
+            torch.cuda.synchronize()
+            self.times[self.name] = self.times.get(self.name, 0.0) + time.perf_counter() - self.t0
+        return False
+
+
 class CogReasoner:
     def __init__(self, vision: VisionEncoder, projector: Projector, llm: Qwen2Engine, config: Optional[LlmConfig] = None,
                  generation_config: Optional[dict] = None, use_token_compression: bool = True):
         self.vision_encoder, self.mm_projector, self.llm = vision, projector, llm
+        if llm is None and config is None:
+            raise ValueError("an encoder-only helper (llm=None, see enable_sharded_encoder) still needs the LlmConfig")
         self.config = config or llm.cfg
-        self.device, self.dtype = llm.device, llm.dtype
+        owner = llm if llm is not None else vision
+        self.device, self.dtype = owner.device, owner.dtype
+        self._shard = None
+        self.stage_times: Optional[Dict[str, float]] = None     # set to {} to collect a per-stage wall-time split
         self.generation_config = dict(DEFAULT_GENERATION if generation_config is None else generation_config)
         self.use_token_compression = use_token_compression
         self.tokenizer = None
@@ -146,7 +169,7 @@ class CogReasoner:
     # ------------------------------------------------------------------ loading
     @classmethod
     def from_pretrained(cls, path: str, torch_dtype=None, device=None, attn_implementation: str = "flash_attention_2",
-                        trust_remote_code: bool = True, **unused) -> "CogReasoner":
+                        trust_remote_code: bool = True, load_llm: bool = True, **unused) -> "CogReasoner":
         """AutoModelForCausalLM.from_pretrained(model_path, trust_remote_code=True, torch_dtype=torch.bfloat16,
         attn_implementation="flash_attention_2") of evaluate/answer_generate.py:173-178 for this implementation:
         config.json / generation_config.json / model.safetensors.index.json + shards of the checkpoint directory.
@@ -175,8 +198,10 @@ class CogReasoner:
         vit_v, proj_v, llm_v = ck.state_views(reader, cfgs["tie_word_embeddings"])
         enc = VisionEncoder(vit_v, cfgs["vision"], dtype=torch_dtype, device=dev, attn_mode=modes[attn_implementation])
         proj = Projector(proj_v, dtype=torch_dtype, device=dev)
-        eng = Qwen2Engine(llm_v, cfgs["llm"], dtype=torch_dtype, device=dev)
-        reader.check_consumed()
+        # load_llm=False: an encoder-only helper rank of a frame-sharded run (enable_sharded_encoder): the 15 GB of
+        # Qwen2 weights are neither read nor held; everything else of the checkpoint must still be consumed
+        eng = Qwen2Engine(llm_v, cfgs["llm"], dtype=torch_dtype, device=dev) if load_llm else None
+        reader.check_consumed(extra_ok=() if load_llm else tuple(llm_v._full(k) for k in llm_v))
         reader.close()
         # HF: generation_config.json, when present, IS the generation config (nothing is merged in from elsewhere);
         # without the file generate() runs on GenerationConfig defaults (greedy, no penalty)
@@ -238,6 +263,69 @@ class CogReasoner:
         this model and the same inputs (same host RNG state for the k-means seeding): parallel.pooled_means_sharded"""
         self._event_rank, self._event_world, self._event_group = int(rank), int(world), group
 
+    def enable_sharded_encoder(self, rank: int, world: int, group=None, payload: str = "projected",
+                               llm_rank: int = 0) -> None:
+        """BASELINE configs[2]: the frames of a request shard data-parallel over `world`
+        processes (one per GPU) that all call qa_selection() / generate() with the SAME inputs -- the reference's
+        launcher contract, evaluate/answer_generate.py:154-158,169-183 (one process per GPU, LOCAL_RANK). Inside
+        encode_images (:264-276) rank r encodes only its contiguous run of frames (parallel.FramePlan) and ONE
+        all-gather (RCCL over xGMI; gloo in rehearsals) reassembles the visual tokens in frame order on every rank.
+          payload "projected": project the local tokens, gather [M, 3584]  (projector work done once, 3.1x the bytes)
+          payload "encoder":   gather the encoder's [M, 1152] tokens, every rank projects all of them
+        The LLM stages run on `llm_rank` only: it owns the retrieval decode of qa_selection (the selection string is
+        broadcast), k-means (assignments broadcast when enable_distributed_events() spreads the event-summary passes,
+        else nobody else needs them), the pixel-difference mask on its full pixel_values, prefill and decode; the new
+        token ids are broadcast so that every rank returns the same answer and multi-turn conversations stay in step.
+        Ranks other than llm_rank may be built without the Qwen2 weights (llm=None / from_pretrained(load_llm=False))
+        unless the event passes are spread. The reference's CPU attention semantics (attn_implementation="eager":
+        every patch attends to every frame) do not shard: in that mode every rank encodes the whole request."""
+        if payload not in ("projected", "encoder"):
+            raise ValueError(f"payload={payload!r}: 'projected' (3584-wide gather) or 'encoder' (1152-wide gather)")
+        if not (0 <= int(rank) < int(world) and 0 <= int(llm_rank) < int(world)):
+            raise ValueError(f"rank {rank} / llm_rank {llm_rank} outside world {world}")
+        if int(rank) == int(llm_rank) and self.llm is None:
+            raise ValueError("the llm_rank needs the Qwen2 weights")
+        self._shard = None if int(world) == 1 else dict(rank=int(rank), world=int(world), group=group, payload=payload,
+                                                        llm_rank=int(llm_rank))
+
+    def _stage(self, name: str):
+        """`with self._stage("encode"):` -- when self.stage_times is a dict, the wall time of the block (device drained
+        on both sides) is added to stage_times[name]; otherwise free. bench.py's `pipeline` split."""
+        return _Stage(self, name)
+
+    def _is_helper(self) -> bool:
+        return self._shard is not None and self._shard["rank"] != self._shard["llm_rank"]
+
+    def _bcast(self, obj, group=None, src: Optional[int] = None):
+        """small python object from one rank (default: the llm_rank of the sharded run) to every rank of the group"""
+        import torch.distributed as dist
+        if src is None:
+            group, src = self._shard["group"], self._shard["llm_rank"]
+        box = [obj]
+        dist.broadcast_object_list(box, src=src if group is None else dist.get_global_rank(group, src), group=group)
+        return box[0]
+
+    def _encode_project(self, pixel_values, grid_sizes, merge_sizes) -> torch.Tensor:
+        """vision_encoder + mm_projector of :270-275 -- on this rank's frames + one all-gather when sharded"""
+        from .vision import REF_EAGER_GLOBAL
+        sh = self._shard
+        if sh is None or self.vision_encoder.attn_mode == REF_EAGER_GLOBAL:
+            return self.mm_projector(self.vision_encoder(pixel_values, grid_sizes, merge_sizes))
+        from .parallel import FramePlan, gather_rows
+        plan = FramePlan(grid_sizes, merge_sizes, sh["world"])
+        px, g, m = plan.local(pixel_values, sh["rank"])
+        wide = sh["payload"] == "projected"
+        width = self.mm_projector.packed.out_dim if wide else self.vision_encoder.cfg.hidden_size
+        if g.shape[0]:
+            tok = self.vision_encoder(px, g, m)
+            if wide:
+                tok = self.mm_projector(tok)
+        else:                                   # more ranks than frames: nothing to encode, still in the collective
+            tok = torch.empty(0, width, device=self.device, dtype=self.dtype)
+        self.last_debug.update(shard_pieces=plan.pieces[sh["rank"]], shard_tokens=plan.token_counts)
+        out = gather_rows(tok, plan.token_counts, sh["group"])
+        return out if wide else self.mm_projector(out)
+
     def enable_prefix_cache(self, on: bool = True) -> None:
         """keep the KV rows of the previous answer prompt and of the previous retrieval prompt (one slot per stage
         and adapter) and prefill only the rows that changed (llm.PrefixKV)"""
@@ -278,7 +366,7 @@ class CogReasoner:
         """:264-276"""
         cache = getattr(self, "_vcache", None)
         if cache is None or video_keys is None or len(video_keys) != int(grid_sizes.shape[0]):
-            return self.mm_projector(self.vision_encoder(pixel_values, grid_sizes, merge_sizes))
+            return self._encode_project(pixel_values, grid_sizes, merge_sizes)
         gs = [tuple(int(x) for x in g) for g in grid_sizes.tolist()]
         ms = [int(m) for m in merge_sizes.tolist()]
         rows = [t * h * w for t, h, w in gs]
@@ -291,7 +379,7 @@ class CogReasoner:
         self.visual_cache_stats["misses"] += len(miss)
         if miss:
             px = pixel_values if len(miss) == len(keys) else torch.cat([pixel_values[offs[v]:offs[v + 1]] for v in miss])
-            tok = self.mm_projector(self.vision_encoder(px, grid_sizes[miss], merge_sizes[miss]))
+            tok = self._encode_project(px, grid_sizes[miss], merge_sizes[miss])
             o = 0
             for v in miss:
                 n = rows[v] // (ms[v] * ms[v])
@@ -320,11 +408,24 @@ class CogReasoner:
         K = math.ceil(T / FRAMES_PER_EVENT)
         if K <= MIN_EVENTS:
             return []
+        spread = getattr(self, "_event_world", 1) > 1
+        if self._is_helper() and not spread:
+            return []        # frame-sharded run: k-means, the event passes and the decision belong to the llm_rank
         features = mm_features.view(T, P, D)
-        centres, _, assign = kmeans_with_time_min_max(features, timestamps, K)
-        picked = select_additional_frames(features, centres, assign, EXTRA_FRAMES)
-        picked_set = set(torch.cat(picked, dim=0).view(-1).tolist())
-        assign_h = assign.cpu().tolist()
+        # spread event passes: ONE rank clusters (the host RNG draws of k-means are that rank's, as in a one-process
+        # run) and broadcasts the T assignments + the near-centroid picks; every rank then builds the same sequences
+        root = self._shard["llm_rank"] if self._shard is not None else 0
+        if not spread or self._event_rank == root:
+            with self._stage("kmeans"):
+                centres, _, assign = kmeans_with_time_min_max(features, timestamps, K)
+                picked = select_additional_frames(features, centres, assign, EXTRA_FRAMES)
+                picked_set = set(torch.cat(picked, dim=0).view(-1).tolist())
+                assign_h = assign.cpu().tolist()
+        if spread:
+            if self.llm is None:
+                raise RuntimeError("enable_distributed_events() needs the Qwen2 weights on every rank")
+            assign_h, picked_set = self._bcast((assign_h, picked_set) if self._event_rank == root else None,
+                                               self._event_group, root)
         ts = timestamps.cpu() if isinstance(timestamps, torch.Tensor) else torch.tensor(timestamps)
         image_id = self.config.image_token_index
         # the K event prompts and the question are K+1 independent sequences: the reference runs one forward per
@@ -342,14 +443,16 @@ class CogReasoner:
             segs.append(idx)
         q = self.tokenizer(self.current_question, padding=True, truncation=True, return_tensors="pt", max_length=128)
         segs.append(q["input_ids"].reshape(-1).to(torch.int64))
-        emb = ops.gather_rows(self.llm.packed.embed, mm_features, torch.cat(segs).to(self.device))
         lens = [int(x.numel()) for x in segs]
-        if getattr(self, "_event_world", 1) > 1:   # enable_distributed_events(): the sequences are spread over the ranks
-            from .parallel import pooled_means_sharded
-            pooled_all = pooled_means_sharded(self.llm.forward_segments, list(emb.split(lens)), self._event_rank,
-                                              self._event_world, self._event_group)
-        else:
-            pooled_all = self.llm.forward_segments(emb, lens)
+        self.last_debug.update(event_tokens=sum(lens))
+        with self._stage("event_prefill"):
+            emb = ops.gather_rows(self.llm.packed.embed, mm_features, torch.cat(segs).to(self.device))
+            if spread:   # enable_distributed_events(): the sequences are spread over the ranks
+                from .parallel import pooled_means_sharded
+                pooled_all = pooled_means_sharded(self.llm.forward_segments, list(emb.split(lens)), self._event_rank,
+                                                  self._event_world, self._event_group)
+            else:
+                pooled_all = self.llm.forward_segments(emb, lens)
         pooled_all = self._bf16_round(pooled_all)  # mean of bf16 is bf16
         qvec, pooled = pooled_all[K], pooled_all[:K]
         cos = self._bf16_round(ops.cosine(qvec.contiguous(), pooled.contiguous())).cpu()
@@ -420,13 +523,16 @@ class CogReasoner:
         if if_visual:
             pixel_values = pixel_values.to(self.device)
             batched = grid_sizes.prod(dim=1).div(merge_sizes ** 2).long()
-            mm = self.encode_images(pixel_values, grid_sizes, merge_sizes, video_keys=video_keys)
+            with self._stage("encode"):
+                mm = self.encode_images(pixel_values, grid_sizes, merge_sizes, video_keys=video_keys)
             text_rows = [m == "text" for m in modals]
             if any(text_rows):  # _get_valid_visual_tokens (:336-347)
                 keep = torch.cat([torch.full((int(n),), not tr, dtype=torch.bool) for n, tr in zip(batched, text_rows)])
                 mm = mm[keep.to(mm.device)].contiguous()
             assert mm.shape[0] % total_image_num == 0, f"{mm.shape[0]} % {total_image_num} != 0"
             frame_indices = self.select_events_based_on_summary(mm, total_image_num, self.all_timestamps)
+            if self._is_helper():       # frame-sharded run: this rank's part (encode, gather, event passes) is done
+                return None, None
             mm = self.compress_unimportant_events(mm, mm.shape[0] // total_image_num, frame_indices)
             mask = self._get_compression_mask(pixel_values, batched, grid_sizes, merge_sizes, modals,
                                               minor_frame_indices=frame_indices)
@@ -440,6 +546,8 @@ class CogReasoner:
             assert int(sel.sum()) == rows.numel(), (int(sel.sum()), rows.numel())
             idx[sel] = -(rows.to(torch.int64) + 1)
         else:
+            if self._is_helper():
+                return None, None
             idx = ids.to(torch.int64)
         embeds = ops.gather_rows(self.llm.packed.embed, mm, idx.to(self.device))
         self.last_debug.update(input_ids=ids)
@@ -476,7 +584,11 @@ class CogReasoner:
         new_ids, new_mask, out_str, vis = input_ids, attention_mask, "", True
         if mode == "FCC":
             if len(hist_qs) > 0:
-                out_str = select_qas(current_question, hist_qs, hist_as, self, tokenizer)
+                if self._shard is None:
+                    out_str = select_qas(current_question, hist_qs, hist_as, self, tokenizer)
+                else:        # frame-sharded run: one retrieval decode on the llm_rank, the string goes to every rank
+                    out_str = self._bcast(None if self._is_helper() else
+                                          select_qas(current_question, hist_qs, hist_as, self, tokenizer))
         elif mode == "AC":
             pass
         elif mode == "NC":
@@ -504,14 +616,18 @@ class CogReasoner:
         total_image_num = kwargs.pop("total_image_num", None)
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")
+        helper = self._is_helper()
         if pixel_values is not None:
             embeds, _ = self.prepare_inputs_labels_for_multimodal(
                 input_ids=new_input_ids, attention_mask=new_attention_mask, pixel_values=pixel_values,
                 grid_sizes=grid_sizes, merge_sizes=merge_sizes, modals=modals, total_image_num=total_image_num,
                 if_visual=if_visual, video_keys=video_keys)
-            embeds = embeds[0]
-        else:
+            embeds = None if helper else embeds[0]
+        elif not helper:
             embeds = self.llm.embed_tokens(new_input_ids.reshape(-1))
+        if helper:     # frame-sharded run: the llm_rank prefills and decodes; its new token ids arrive by broadcast
+            got = self._bcast(None)
+            return torch.tensor(got, dtype=torch.int64).reshape(1, len(got)), selection_module_output
         g = dict(self.generation_config)
         g.update({k: v for k, v in kwargs.items() if k in ("do_sample", "temperature", "top_k", "top_p",
                                                             "repetition_penalty", "eos_token_id", "generator",
@@ -519,9 +635,12 @@ class CogReasoner:
         eos = g.get("eos_token_id", [])
         eos = [eos] if isinstance(eos, int) else list(eos)
         new = self.llm.generate(embeds, max_new_tokens=int(kwargs.get("max_new_tokens", 1024)), eos_token_id=eos,
+                                stage_times=self.stage_times,
                                 do_sample=bool(g.get("do_sample", False)), temperature=float(g.get("temperature", 1.0)),
                                 top_k=int(g.get("top_k", 0) or 0), top_p=float(g.get("top_p", 1.0)),
                                 repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"),
                                 sampler=g.get("sampler", "device"), seed=g.get("seed"),
                                 prefix=self._prefix_slot("answer"))
+        if self._shard is not None:
+            self._bcast(list(new))
         return torch.tensor(new, dtype=torch.int64).unsqueeze(0), selection_module_output

@@ -297,3 +297,26 @@ def save_checkpoint(path: str, vit_state, proj_state, llm_state, vision: VisionC
                                 "AutoProcessor": "processing_cogreasoner.Videollama3Qwen2Processor"},
                    "image_mean": [0.5, 0.5, 0.5], "image_std": [0.5, 0.5, 0.5], "max_tokens": 16384, "min_tokens": 16,
                    "patch_size": 14, "resample": 3, "rescale_factor": 1 / 255}, f, indent=1)
+
+
+def save_byte_tokenizer(path: str) -> None:
+    """tokenizer files for SYNTHETIC checkpoints (tests, rehearsals): a genuine Qwen2TokenizerFast -- the class
+    load_tokenizer() returns for the real checkpoint -- over a byte-level vocabulary without merges (ids 0..255 = UTF-8
+    bytes) plus the chat specials at 256..259 (<|im_start|>, <|im_end|>, <image>, <|endoftext|>). The real vocab.json /
+    merges.txt are reference data that does not ship with this repo."""
+    from transformers import Qwen2TokenizerFast
+    # GPT-2's printable stand-ins for the 256 byte values (what a byte-level BPE vocabulary is keyed by)
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAC + 1)) + list(range(0xAE, 0xFF + 1))
+    cs = bs[:]
+    for b in range(256):
+        if b not in bs:          # the 68 unprintable bytes map to code points 256, 257, ...
+            cs.append(256 + len(bs) - 188)
+            bs.append(b)
+    vocab = {chr(c): b for b, c in zip(bs, cs)}
+    specials = ["<|im_start|>", "<|im_end|>", "<image>", "<|endoftext|>"]
+    for i, t in enumerate(specials):
+        vocab[t] = 256 + i
+    tok = Qwen2TokenizerFast(vocab=vocab, merges=[], unk_token=None, eos_token="<|im_end|>", pad_token="<|endoftext|>",
+                             additional_special_tokens=specials)
+    os.makedirs(path, exist_ok=True)
+    tok.save_pretrained(path)

@@ -139,7 +139,8 @@ class Qwen2Engine:
                  prompt_ids: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
                  sampler: str = "device", seed: Optional[int] = None,
                  cache: Optional[KVCache] = None, ignore_eos: bool = False,
-                 prefix: Optional[PrefixKV] = None, prefilled: Optional[dict] = None) -> List[int]:
+                 prefix: Optional[PrefixKV] = None, prefilled: Optional[dict] = None,
+                 stage_times: Optional[dict] = None) -> List[int]:
         """GenerationMixin.generate with inputs_embeds: prefill, then one cogs_llm_forward per token.
         Returns the NEW token ids only. Logits processors run in HF order:
         repetition penalty -> custom (allowed-id mask) -> temperature -> top-k -> top-p.
@@ -151,6 +152,10 @@ class Qwen2Engine:
         (`generator`, default the global one) makes the [vocab] exponential draws of every step exactly as
         torch.multinomial does in the reference's CPU run, so the sampled ids are the reference's."""
         S = embeds.shape[0]
+        if stage_times is not None:        # bench.py's pipeline split: the prompt pass and the token loop, drained on both sides
+            import time
+            torch.cuda.synchronize()
+            t_start = time.perf_counter()
         if prefilled is not None:
             assert cache is not None and prefix is None and cache.len >= S and "logits" in prefilled
             pos_start = cache.len
@@ -170,6 +175,10 @@ class Qwen2Engine:
                 cache = self.new_cache(S + max_new_tokens)
             pos_start = cache.len + S
             res = self.forward(embeds, cache)
+        if stage_times is not None:
+            torch.cuda.synchronize()
+            t_loop = time.perf_counter()
+            stage_times["answer_prefill"] = stage_times.get("answer_prefill", 0.0) + t_loop - t_start
         allowed = (torch.tensor(list(allowed_ids), dtype=torch.int32, device=self.device) if allowed_ids is not None else None)
         eos = set(int(e) for e in eos_token_id)
         # token ids stay on the device: the greedy id feeds the next embedding gather and the repetition-penalty
@@ -212,6 +221,8 @@ class Qwen2Engine:
             if not last:
                 res = self.forward(self.embed_tokens(tok_dev), cache)
         out = toks[:produced].tolist()
+        if stage_times is not None:
+            stage_times["decode"] = stage_times.get("decode", 0.0) + time.perf_counter() - t_loop
         if stop_at is not None:
             out = out[:stop_at]
             # forwards issued past the EOS only wrote KV rows that are dropped again here

@@ -15,7 +15,7 @@ to ~100 GB/s; no multi-GPU node was available to the builder, so these are estim
 bench.py measure the real thing.)"""
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -40,29 +40,95 @@ def shard_video(pixel_values: torch.Tensor, grid_size: Tuple[int, int, int], ran
     return pixel_values[b * per:e * per], torch.tensor([[e - b, gh, gw]])
 
 
+def _world_gather(local: torch.Tensor, out: torch.Tensor, group=None) -> None:
+    """all_gather_into_tensor, staged through host memory when the tensors are on a GPU but the group is gloo (CPU
+    tests and one-GPU rehearsals only; on a node the backend is nccl = RCCL and nothing leaves HBM / xGMI)"""
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+
+
+def gather_rows(local: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
+    """all-gather row blocks of known sizes (`counts[r]` rows on rank r, every rank knows all of them) -> the
+    concatenation in rank order, on every rank. Equal counts: one collective straight into the result. Ragged:
+    collectives need equal counts, so every block is padded to the largest one and the padding trimmed after."""
+    world = len(counts)
+    if world == 1:
+        return local
+    width = local.shape[1]
+    rows = max(int(c) for c in counts)
+    if all(int(c) == rows for c in counts):
+        out = torch.empty(world * rows, width, dtype=local.dtype, device=local.device)
+        _world_gather(local, out, group)
+        return out
+    padded = local.new_zeros(rows, width)
+    padded[: local.shape[0]] = local
+    out = torch.empty(world * rows, width, dtype=local.dtype, device=local.device)
+    _world_gather(padded, out, group)
+    return torch.cat([out[r * rows: r * rows + int(c)] for r, c in enumerate(counts) if int(c) > 0], dim=0)
+
+
 def gather_tokens(local_tokens: torch.Tensor, grid_size: Tuple[int, int, int], merge_size: int, world: int,
                   group=None) -> torch.Tensor:
-    """all-gather the per-rank merged tokens back into frame order -> [M, hidden] on every rank"""
+    """all-gather the per-rank merged tokens of ONE video back into frame order -> [M, hidden] on every rank"""
     if world == 1:
         return local_tokens
     t, gh, gw = (int(v) for v in grid_size)
     ppf = (gh // merge_size) * (gw // merge_size)
-    shards = frame_shards(t, world)
-    if local_tokens.is_cuda and dist.get_backend(group) == "gloo":
-        # gloo has no device all-gather: stage through host memory (CPU tests and one-GPU rehearsals only;
-        # on a node the backend is nccl = RCCL and the tensors never leave HBM / xGMI)
-        return gather_tokens(local_tokens.cpu(), grid_size, merge_size, world, group).to(local_tokens.device)
-    if all(e - b == shards[0][1] - shards[0][0] for b, e in shards):
-        out = torch.empty(t * ppf, local_tokens.shape[1], dtype=local_tokens.dtype, device=local_tokens.device)
-        dist.all_gather_into_tensor(out, local_tokens.contiguous(), group=group)
-        return out
-    # ragged split: collectives need equal counts, so pad every shard to the largest one and trim after
-    rows = max(e - b for b, e in shards) * ppf
-    padded = local_tokens.new_zeros(rows, local_tokens.shape[1])
-    padded[: local_tokens.shape[0]] = local_tokens
-    out = torch.empty(world * rows, local_tokens.shape[1], dtype=local_tokens.dtype, device=local_tokens.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
-    return torch.cat([out[r * rows: r * rows + (e - b) * ppf] for r, (b, e) in enumerate(shards)], dim=0)
+    return gather_rows(local_tokens, [(e - b) * ppf for b, e in frame_shards(t, world)], group)
+
+
+class FramePlan:
+    """Which frames of a request (several videos, each t x gh x gw patches) a rank encodes.
+    The frames of all videos in order form one sequence; it is cut into `world` CONTIGUOUS runs whose patch counts
+    are as even as frame boundaries allow (cut r sits at the frame boundary nearest to r/world of the patches), so
+    the gathered tokens are already in the reference's order (video -> frame -> token). Every rank derives the same
+    plan from grid_sizes / merge_sizes alone.
+
+      pieces[r]       [(video, first frame, end frame), ...] of rank r (empty when there are more ranks than frames)
+      patch_rows[r]   (begin, end) rows of pixel_values          token_counts[r]   merged tokens rank r produces"""
+
+    def __init__(self, grid_sizes, merge_sizes, world: int):
+        gs = [[int(x) for x in g] for g in (grid_sizes.tolist() if hasattr(grid_sizes, "tolist") else grid_sizes)]
+        ms = [int(m) for m in (merge_sizes.tolist() if hasattr(merge_sizes, "tolist") else merge_sizes)]
+        frames = [(v, f, gh * gw, (gh // m) * (gw // m)) for v, ((t, gh, gw), m) in enumerate(zip(gs, ms)) for f in range(t)]
+        cum = [0]
+        for _, _, n, _ in frames:
+            cum.append(cum[-1] + n)
+        total = cum[-1]
+        cuts = [0]
+        for r in range(1, world):
+            target = total * r / world
+            # nearest frame boundary at or after the previous cut (ties to the earlier boundary)
+            j = min(range(cuts[-1], len(cum)), key=lambda i: (abs(cum[i] - target), i))
+            cuts.append(j)
+        cuts.append(len(frames))
+        self.world, self.grids, self.merges = world, gs, ms
+        self.pieces: List[List[Tuple[int, int, int]]] = []
+        self.patch_rows: List[Tuple[int, int]] = []
+        self.token_counts: List[int] = []
+        for r in range(world):
+            run = frames[cuts[r]:cuts[r + 1]]
+            pcs: List[Tuple[int, int, int]] = []
+            for v, f, _, _ in run:
+                if pcs and pcs[-1][0] == v and pcs[-1][2] == f:
+                    pcs[-1] = (v, pcs[-1][1], f + 1)
+                else:
+                    pcs.append((v, f, f + 1))
+            self.pieces.append(pcs)
+            self.patch_rows.append((cum[cuts[r]], cum[cuts[r + 1]]))
+            self.token_counts.append(sum(m for _, _, _, m in run))
+
+    def local(self, pixel_values: torch.Tensor, rank: int):
+        """-> (rows of this rank's frames (a view), grid_sizes [n,3], merge_sizes [n]) for the encoder call"""
+        b, e = self.patch_rows[rank]
+        pcs = self.pieces[rank]
+        grid = torch.tensor([[fe - fb, self.grids[v][1], self.grids[v][2]] for v, fb, fe in pcs], dtype=torch.int64).reshape(-1, 3)
+        merge = torch.tensor([self.merges[v] for v, _, _ in pcs], dtype=torch.int64)
+        return pixel_values[b:e], grid, merge
 
 
 def partition_sequences(lengths, world: int) -> List[List[int]]:

@@ -275,6 +275,7 @@ class CogStreamProcessor:
         self.video_merge_size = video_merge_size
         self.max_tokens, self.min_tokens = max_tokens, min_tokens
         self.device, self.pixel_dtype = device, pixel_dtype
+        self.video_loader = None      # path -> video_io.DecodedVideo; default video_io.read_decoded_video (.npz)
 
     @classmethod
     def from_pretrained(cls, path: str, device=None, pixel_dtype=None, trust_remote_code: bool = True, tokenizer=None,
@@ -294,6 +295,15 @@ class CogStreamProcessor:
                  add_generation_prompt: bool = True, return_tensors: str = "pt") -> Dict[str, Any]:
         import torch
 
+        # file-backed clips ({"video": {"video_path": ..., "fps": 1, "max_frames": 180}}, evaluate/answer_generate.py:126):
+        # sampled at fps, cut to max_frames, timestamps stitched across segments -- _load_multimodal_data (:431-509)
+        if any(isinstance(c, dict) and c.get("type") == "video" and isinstance(c.get("video"), dict)
+               for m in conversation if isinstance(m["content"], (list, tuple)) for c in m["content"]):
+            from .video_io import load_multimodal_data, read_decoded_video
+            paths = {c["video"]["video_path"] for m in conversation if isinstance(m["content"], (list, tuple))
+                     for c in m["content"] if isinstance(c, dict) and c.get("type") == "video" and isinstance(c.get("video"), dict)}
+            loader = self.video_loader or read_decoded_video
+            conversation, _ = load_multimodal_data(conversation, {p: loader(p) for p in sorted(paths)})
         videos, all_ts, conv = [], [], []
         for msg in conversation:
             if isinstance(msg["content"], str):

@@ -345,6 +345,85 @@ def golden_e2e():
     save("e2e.npz", **out)
 
 
+def golden_e2e_blockdiag():
+    """cases b and c of golden_e2e with the encoder in the semantics the reference SHIPS with on a GPU
+    (flash_attention_2: per-frame block-diagonal attention, modeling_videollama3_encoder.py:309-312). flash_attn is
+    not installable here, so the reference's eager encoder is called ONE FRAME PER CALL inside the reference's own
+    encode_images (the +1 same-frame bias is constant over a single frame, hence softmax-invariant: golden_vit's
+    construction). This is the mode the frame-sharded encoder runs in, so the N-rank pipeline
+    tests are checked against it. Everything downstream -- k-means, event passes, compression, generate -- is the
+    reference unchanged."""
+    vst = random_vit_state(VisionConfig(**VIT), seed=3, std=0.05)
+    pst = random_proj_state(VIT["hidden_size"], LLM["hidden_size"], seed=1, std=0.05)
+    lst = random_llm_state(LlmConfig(**LLM), seed=7, std=0.05)
+    model = build_ref_model(vst, pst, lst)
+    venc = model.get_model().get_vision_encoder()
+    whole = venc.forward
+
+    def per_frame(pixel_values, grid_sizes, merge_sizes):
+        outs, row = [], 0
+        for (t, h, w), ms in zip(grid_sizes.tolist(), merge_sizes.tolist()):
+            for _ in range(t):
+                outs.append(whole(pixel_values[row:row + h * w], torch.tensor([[1, h, w]]), torch.tensor([ms])))
+                row += h * w
+        return torch.cat(outs, 0)
+
+    venc.forward = per_frame
+    tok = ToyTokenizer()
+    out = {"vit_checksum": np.float64(checksum(vst)), "llm_checksum": np.float64(checksum(lst))}
+    for tag in ("b", "c"):
+        inp = e2e_inputs(tag)
+        enc = tok(inp["text"])
+        random.seed(5)
+        torch.manual_seed(5)
+        cap = {}
+        sel = model.qa_selection(current_question=inp["current_question"], hist_qs=inp["hist_qs"], hist_as=inp["hist_as"],
+                                 tokenizer=tok, original_text=inp["text"], input_ids=enc["input_ids"],
+                                 attention_mask=enc["attention_mask"], mode="FCC", all_timestamps=inp["timestamps"])
+        orig_sel, orig_mask = model.select_events_based_on_summary, model._get_compression_mask
+        orig_cos, orig_km = ref_chat.F.cosine_similarity, ref_chat.kmeans_with_time_min_max
+        forced = torch.tensor(FORCED_COSINE)
+
+        def wrap_sel(mm, n, t_):
+            r = orig_sel(mm, n, t_)
+            cap["minor"] = list(r)
+            return r
+
+        def wrap_mask(*a, **k):
+            r = orig_mask(*a, **k)
+            cap["mask"] = r.clone()
+            return r
+
+        def wrap_cos(a, b, dim=1):
+            r = orig_cos(a, b, dim=dim)
+            cap["cosine"] = r.clone()
+            return forced.to(r.dtype) if tag == "c" else r
+
+        def wrap_km(f, t_, k):
+            r = orig_km(f, t_, k)
+            cap["assign"] = r[2].clone()
+            return r
+
+        model.select_events_based_on_summary, model._get_compression_mask = wrap_sel, wrap_mask
+        ref_chat.F.cosine_similarity, ref_chat.kmeans_with_time_min_max = wrap_cos, wrap_km
+        try:
+            new_ids, sel_str = model.generate(pixel_values=inp["pixel_values"], grid_sizes=inp["grid_sizes"],
+                                              merge_sizes=inp["merge_sizes"], modals=["video"],
+                                              new_input_ids=sel["new_input_ids"], new_attention_mask=sel["new_attention_mask"],
+                                              selection_module_output=sel["selection_module_output"],
+                                              if_visual=sel["if_visual"], total_image_num=inp["T"], max_new_tokens=8,
+                                              do_sample=False, repetition_penalty=1.05)
+        finally:
+            model.select_events_based_on_summary, model._get_compression_mask = orig_sel, orig_mask
+            ref_chat.F.cosine_similarity, ref_chat.kmeans_with_time_min_max = orig_cos, orig_km
+        out.update({f"{tag}_pix_checksum": np.float64(inp["pixel_values"].double().abs().sum()),
+                    f"{tag}_minor": np.array(cap["minor"], dtype=np.int64), f"{tag}_mask": cap["mask"],
+                    f"{tag}_tokens": new_ids[0], f"{tag}_cosine": cap["cosine"], f"{tag}_assign": cap["assign"]})
+        print(tag, "block-diagonal: minor frames", len(cap["minor"]), "kept tokens", int(cap["mask"].sum()),
+              "new tokens", new_ids[0].tolist())
+    save("e2e_blockdiag.npz", **out)
+
+
 QWEN2_CASES = {
     # tag: (LlmConfig overrides, prompt length)  -- "t" = the tiny e2e model; "g" = GQA with 3 query heads per kv head
     "t": (dict(LLM), 37),
@@ -841,7 +920,7 @@ if __name__ == "__main__":
     if "--only-preprocess" in sys.argv:
         golden_preprocess()
         sys.exit(0)
-    which = sys.argv[1:] or ["preprocess", "vit", "vit_bf16", "kmeans", "kmeans_reseed", "compress", "text", "e2e", "qwen2", "lora"]
+    which = sys.argv[1:] or ["preprocess", "vit", "vit_bf16", "kmeans", "kmeans_reseed", "compress", "text", "e2e", "e2e_blockdiag", "qwen2", "lora"]
     with torch.no_grad():
         for w in which:
             globals()["golden_" + w]()

@@ -26,6 +26,56 @@ def test_flop_model_matches_survey_figures():
     assert abs((enc1 - 64 * proj) / 1e9 - 219) < 3 and abs((enc3 - 50 * proj) / 1e9 - 170) < 3
 
 
+def test_bench_tokenizer_reproduces_the_real_prompt_lengths():
+    """bench.PromptLengthTokenizer stands in for the checkpoint's Qwen2 tokenizer (whose vocabulary does not ship) in the
+    `pipeline` / cfg5 timings: its token COUNTS on the bench's prompts equal the real tokenizer's, as recorded in
+    tests/golden/tokenizer.json (cfg2 15 395, cfg1 621, cfg3 15 295 prompt tokens; event-summary prompt 974)"""
+    import torch
+    import bench
+    from cogstream_amd import processing as pr
+    from cogstream_amd.chat import create_visual_summary_prompt
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "tokenizer.json")))
+    tok = bench.PromptLengthTokenizer()
+    assert [p["len"] for p in fx["prompts"]] == [15395, 621, 15295]
+    for p in fx["prompts"]:
+        T, P = p["T"], p["P"]
+        conv = [{"role": "user", "content": [{"type": "video", "num_frames": T, "timestamps": [float(i) for i in range(T)]},
+                                             {"type": "text", "text": p["question"]}]}]
+        text = pr.expand_image_tokens(pr.render_conversation(conv, True, True), [P] * T)
+        ids = tok(text)["input_ids"]
+        assert ids.shape == (1, p["len"]) and bench.prompt_tokens(T, P) == p["len"]
+        assert int((ids == fx["image_token_id"]).sum()) == T * P and int(ids[0, 0]) == fx["im_start"]
+    sp = create_visual_summary_prompt(15 * 50, torch.arange(15, dtype=torch.float32) + 30)
+    assert tok(sp)["input_ids"].shape[1] == fx["summary_prompt_len"] == 974
+
+
+def test_bench_gpus_n_launches_its_own_ranks_without_touching_the_gpu(monkeypatch, capsys):
+    """`python bench.py --gpus 4` outside torch.distributed.run: the parent builds the launcher command for 4 fresh rank
+    processes with the same flags on 127.0.0.1, relays rank 0's JSON line and returns their status"""
+    import io
+    import subprocess
+    import bench
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, **kw):
+            seen["cmd"], seen["env"] = cmd, kw["env"]
+            self.stdout = io.StringIO("noise from a rank\n{\"metric\": \"m\", \"n_gpus\": 4}\n")
+
+        def wait(self):
+            return 3
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.launch_ranks(4) == 3
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert cmd[-5].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "m", "n_gpus": 4}' and "noise from a rank" in out.err
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     env = dict(os.environ, PYTHONPATH=ROOT)

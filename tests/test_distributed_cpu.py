@@ -114,3 +114,60 @@ def test_event_summary_sequences_shard_over_two_ranks():
     for rank, same, calls in res:
         assert same
         assert calls == [[lens[i] for i in plan[rank]]]     # ONE var-len forward per rank, over its share only
+
+
+def test_frame_plan_cuts_at_frame_boundaries_and_covers_every_frame():
+    """parallel.FramePlan: contiguous runs of whole frames, balanced by patches, every frame exactly once, the same
+    plan on every rank; more ranks than frames leaves ranks empty"""
+    from cogstream_amd.parallel import FramePlan
+    p = FramePlan(torch.tensor([[256, 10, 20]]), torch.tensor([2]), 8)        # BASELINE configs[2] over 8 GPUs
+    assert p.pieces == [[(0, 32 * r, 32 * r + 32)] for r in range(8)] and p.token_counts == [1600] * 8
+    assert p.patch_rows[3] == (19200, 25600)
+    grids, merges = torch.tensor([[3, 4, 6], [2, 2, 4], [5, 4, 4]]), torch.tensor([2, 2, 2])
+    for world in (1, 2, 3, 4, 7, 16):
+        p = FramePlan(grids, merges, world)
+        flat = [(v, f) for pcs in p.pieces for v, b, e in pcs for f in range(b, e)]
+        assert flat == [(v, f) for v, t in enumerate((3, 2, 5)) for f in range(t)]
+        assert p.patch_rows[0][0] == 0 and p.patch_rows[-1][1] == 3 * 24 + 2 * 8 + 5 * 16
+        assert all(a[1] == b[0] for a, b in zip(p.patch_rows, p.patch_rows[1:]))
+        assert sum(p.token_counts) == (3 * 24 + 2 * 8 + 5 * 16) // 4
+    px, g, m = FramePlan(grids, merges, 4).local(torch.arange(168 * 2).view(168, 2), 1)
+    assert g.tolist() == [[1, 4, 6], [1, 2, 4]] and m.tolist() == [2, 2] and px[0, 0].item() == 48 * 2 and px.shape[0] == 32
+
+
+def _ragged_worker(rank, world, port, counts, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cogstream_amd.parallel import gather_rows
+    local = torch.full((counts[rank], 3), float(rank + 1)) + torch.arange(counts[rank])[:, None]
+    got = gather_rows(local, counts)
+    q.put((rank, got.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_rows_ragged_and_empty_shards():
+    ctx = mp.get_context("spawn")
+    for counts in ([3, 1], [0, 2], [2, 2]):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, counts, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        want = [[float(r + 1 + i)] * 3 for r, c in enumerate(counts) for i in range(c)]
+        assert res[0] == want and res[1] == want
+
+
+def test_sampler_indices_equal_torch_distributed_sampler():
+    """answer_generate.sampler_indices is DistributedSampler(dataset, num_replicas, rank) of the reference driver
+    (evaluate/answer_generate.py:186): shuffled under seed 0, padded by wrap-around"""
+    from torch.utils.data.distributed import DistributedSampler
+    from cogstream_amd.answer_generate import sampler_indices
+    for n, w in ((10, 4), (3, 8), (8, 8), (1, 2), (17, 3)):
+        for r in range(w):
+            assert list(DistributedSampler(list(range(n)), num_replicas=w, rank=r)) == sampler_indices(n, r, w)
+            assert list(DistributedSampler(list(range(n)), num_replicas=w, rank=r, shuffle=False)) == sampler_indices(n, r, w, shuffle=False)

@@ -276,7 +276,7 @@ def test_bench_cfg3_mode_and_extra_key(dev):
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["config"]["frames"] == 64 and d["scaling"] == "weak" and d["cfg3"]["frames_per_gpu"] == 256
+    assert d["config"]["frames"] == 64 and d["scaling"] == "strong" and d["cfg3"]["frames_per_gpu"] == 256 and d["ranks_seen"] == 1
     assert "140x280" in d["cfg3"]["workload"] and d["cfg3"]["value"] > 0
     assert d["roofline"]["traffic_source"] is None or "not this run" in d["roofline"]["traffic_source"]
 

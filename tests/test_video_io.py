@@ -59,3 +59,68 @@ def test_fps_filter_round_up_slots():
     assert vio.select_frames(v, 2.5, False, 0.0, 1.0).tolist() == [0, 4, 8, 9]
     assert vio.select_frames(v, 1.0, True, 0.0, 1.0).tolist() == [0, 3]          # -t 1.0 keeps pts < 1.0
     assert vio.select_frames(v, 2.5, False, 0.0, None).tolist() == list(range(10))
+
+
+def test_driver_loop_over_decoded_segment_files_on_a_stub_model(tmp_path):
+    """answer_generate.answer_video = the per-video body of the reference's inference() (evaluate/answer_generate.py:
+    106-148): segments grouped by Event_Time and zipped with the naturally sorted segment files, every question
+    answered with the whole conversation so far, records in the reference's result format. The clips are decoded-frame
+    files (video_io.write_decoded_video) that the processor samples at 1 fps / max_frames 180 with timestamps stitched
+    across segments. The model is a stub (CPU): what is checked is the driver and the processor, not the kernels."""
+    import json
+    import os
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.dirname(__file__))
+    from toy_tokenizer import ToyTokenizer
+    from cogstream_amd import processing as pr
+    from cogstream_amd.answer_generate import VideoDataset, answer_video, natural_sort_segments, save_to_json
+    from cogstream_amd.video_io import read_decoded_video, write_decoded_video
+
+    vdir, qdir = tmp_path / "videos", tmp_path / "queries"
+    (vdir / "clipA").mkdir(parents=True)
+    qdir.mkdir()
+    for s, n in ((0, 6), (1, 8), (10, 4)):        # segment_10 sorts after segment_1 (natural order), 2 fps native
+        fr, _ = pr.synthetic_clip(n, 56, 84, kind="drift", clip_idx=s)
+        write_decoded_video(str(vdir / "clipA" / f"segment_{s}.npz"), fr, native_fps=2.0)
+    assert natural_sort_segments(str(vdir / "clipA")) == ["segment_0.npz", "segment_1.npz", "segment_10.npz"]
+    dv = read_decoded_video(str(vdir / "clipA" / "segment_1.npz"))
+    assert dv.frames.shape == (8, 56, 84, 3) and dv.native_fps == 2.0
+    chain = [{"Q": "q0?", "A": "a0", "info": {"Event_Time": 3, "relevance": []}},
+             {"Q": "q1?", "A": "a1", "info": {"Event_Time": 3, "relevance": [1]}},
+             {"Q": "q2?", "A": "a2", "info": {"Event_Time": 7, "relevance": [0, 1]}},
+             {"Q": "q3?", "A": "a3", "info": {"Event_Time": 9, "relevance": [0, 0, 1]}}]
+    json.dump([chain], open(qdir / "clipA.json", "w"))
+    json.dump([chain], open(qdir / "missing_video.json", "w"))
+    ds = VideoDataset(str(vdir), str(qdir))
+    assert len(ds) == 1 and ds[0]["video_path"].endswith("clipA") and ds[0]["query_chain"] == chain
+
+    class Stub:
+        device, dtype, _adapters = torch.device("cpu"), torch.float32, {}
+        calls = []
+
+        def qa_selection(self, **kw):
+            n = len(kw["hist_qs"])
+            self.calls.append((n, kw["pixel_values"].shape[0], list(kw["all_timestamps"]), kw["current_question"]))
+            sel = "" if n == 0 else "[" + ",".join(["yes"] + [str(i) for i in range(0, n, 2)]) + "]"
+            return {**kw, "new_input_ids": kw["input_ids"], "new_attention_mask": kw["attention_mask"],
+                    "selection_module_output": sel, "if_visual": True}
+
+        def generate(self, **kw):
+            return torch.tensor([[ord("o"), ord("k"), 48 + len(kw["hist_qs"])]]), kw["selection_module_output"]
+
+    model = Stub()
+    data = answer_video(model, pr.CogStreamProcessor(ToyTokenizer()), ds[0]["video_path"], ds[0]["query_chain"], max_new_tokens=3)
+    recs = data[0]
+    assert [r["qa_id"] for r in recs] == [0, 1, 2, 3] and [r["prediction"] for r in recs] == ["ok0", "ok1", "ok2", "ok3"]
+    assert [r["predicted_coi"] for r in recs] == [[], [1], [1, 0], [1, 0, 1]] and [r["coi"] for r in recs] == [[], [1], [0, 1], [0, 0, 1]]
+    assert [r["answer"] for r in recs] == ["a0", "a1", "a2", "a3"] and all(r["predicted_visual"] for r in recs)
+    # the conversation grows by one clip per segment: 4 frames (6 at 2 fps -> 1 fps, round up), then + 4, then + 2; the 1 fps
+    # timestamp grid continues across the segments
+    n_hist, n_patch, ts, q = zip(*model.calls)
+    assert n_hist == (0, 1, 2, 3) and q == ("q0?", "q1?", "q2?", "q3?")
+    assert [len(t) for t in ts] == [4, 4, 8, 10] and list(ts[3]) == sorted(ts[3]) and ts[3][:4] == ts[0]
+    assert len(set(ts[3])) == 10
+    path = save_to_json("clipA", data, str(tmp_path / "out"))
+    assert json.load(open(path)) == {"video_name": "clipA", "Data": data}
