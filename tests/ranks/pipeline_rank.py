@@ -53,6 +53,7 @@ def main():
     g = {k: v for k, v in np.load(os.path.join(ROOT, "tests", "golden", "e2e_blockdiag.npz")).items()}
     tok = ToyTokenizer()
     ok = True
+    records = []
     for tag in ("b", "c"):
         inp = e2e_inputs(tag)
         ids = tok(inp["text"])
@@ -77,8 +78,13 @@ def main():
                       "cosine": float((d["cosine_raw"] - torch.from_numpy(g[f"{tag}_cosine"])).abs().max()) < 1e-3}
             rec["checks"] = checks
             ok = ok and all(checks.values())
-        print("RANK_RECORD " + json.dumps(rec), flush=True)
+        records.append(rec)
+    every = [None] * world
+    dist.all_gather_object(every, records)       # one writer: lines of two processes on one pipe can interleave
     if rank == 0:
+        for recs in every:
+            for rec in recs:
+                print("RANK_RECORD " + json.dumps(rec), flush=True)
         print("PIPELINE_RESULT", "OK" if ok else "MISMATCH", flush=True)
     dist.barrier()
     dist.destroy_process_group()
