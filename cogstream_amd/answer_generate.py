@@ -266,7 +266,9 @@ def main(argv=None) -> int:
     else:
         indices, save_dir = sampler_indices(len(dataset), rank, world), args.save_dir
     written = inference(model, dataset, indices, processor, save_dir, args.max_new_tokens, **gen)
-    print(f"rank {rank}/{world} ({args.mode}): {len(indices)} videos answered, {len(written)} result files written", flush=True)
+    import sys
+    sys.stdout.write(f"rank {rank}/{world} ({args.mode}): {len(indices)} videos answered, {len(written)} result files written\n")
+    sys.stdout.flush()          # one write per line: the ranks share the launcher's pipe
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
