@@ -430,7 +430,8 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
         nframes += t;
     }
     static const bool env_single = getenv("COGS_VIT_STREAMS") && atoi(getenv("COGS_VIT_STREAMS")) == 1;
-    if (!env_single && !h->prof_on && attn_mode == COGS_ATTN_BLOCK_DIAG && nframes >= 2 && N <= VIT_SPLIT_MAX_PATCHES) {
+    static const int64_t split_max = getenv("COGS_VIT_SPLIT_MAX") ? atoll(getenv("COGS_VIT_SPLIT_MAX")) : VIT_SPLIT_MAX_PATCHES;
+    if (!env_single && !h->prof_on && attn_mode == COGS_ATTN_BLOCK_DIAG && nframes >= 2 && N <= split_max) {
         // cut at the frame boundary nearest to half the patches
         std::vector<int64_t> ga, gb, ma, mb;
         int64_t rows_a = 0, toks_a = 0, fa = 0, best_gap = N + 1, acc = 0;

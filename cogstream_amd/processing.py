@@ -46,6 +46,33 @@ def simple_batched_resize(sizes: Sequence[Tuple[int, int]], num_images: int, fac
     return out
 
 
+def batched_resize(shapes: Sequence[Tuple[int, int, int]], factors: Sequence[int], min_tokens: int = 16,
+                   max_tokens: int = 16384) -> List[Tuple[int, int]]:
+    """image_processing_videollama3.py:134-173 -- the size rule for a batch whose items have DIFFERENT merge sizes (an
+    image next to a clip): `shapes` = (frames, height, width) per item, `factors` = 14 * merge_size per item. One
+    common scale sqrt(total_tokens / max_tokens) when the batch is over budget, else round to the factor."""
+    total = sum(n * math.ceil(h / f) * math.ceil(w / f) for (n, h, w), f in zip(shapes, factors))
+    out = []
+    if total > max_tokens:
+        beta = math.sqrt(total / max_tokens)
+        for (_, h, w), f in zip(shapes, factors):
+            out.append((math.floor(h / beta / f) * f, math.floor(w / beta / f) * f))
+    else:
+        for (_, h, w), f in zip(shapes, factors):
+            out.append((round(h / f) * f, round(w / f) * f))
+    return out
+
+
+def media_target_sizes(shapes: Sequence[Tuple[int, int, int]], merge_sizes: Sequence[int], min_tokens: int = 16,
+                       max_tokens: int = 16384) -> List[Tuple[int, int]]:
+    """Videollama3ImageProcessor.preprocess's choice (:424-439): one merge size for every item -> simple_batched_resize
+    with factor 14 * merge (the budget is shared by all frames); mixed merge sizes -> batched_resize"""
+    if all(m == merge_sizes[0] for m in merge_sizes):
+        return simple_batched_resize([(h, w) for _, h, w in shapes], sum(n for n, _, _ in shapes),
+                                     PATCH * merge_sizes[0], min_tokens, max_tokens)
+    return batched_resize(shapes, [PATCH * m for m in merge_sizes], min_tokens, max_tokens)
+
+
 def patchify(frames: np.ndarray, merge_size: int) -> np.ndarray:
     """[t, c, H, W] -> [t*gh*gw, c*14*14], rows ordered frame -> merge-row -> merge-col -> window (dy,dx),
     elements (c, py, px)   (image_processing_videollama3.py:326-345)"""
@@ -147,25 +174,31 @@ def pixel_value_table(rescale_factor: float = 0.00392156862745098, image_mean=(0
     return np.ascontiguousarray(((x[None, :] - mean) / std).astype(np.float32))
 
 
-def preprocess_videos(videos: Sequence[np.ndarray], merge_size: int = 2, min_tokens: int = 16,
-                      max_tokens: int = 16384) -> Dict[str, np.ndarray]:
-    """Videollama3ImageProcessor.preprocess (:349-473) for a list of clips, each uint8 [t, H, W, 3].
+def preprocess_media(items: Sequence[np.ndarray], merge_sizes: Sequence[int], min_tokens: int = 16,
+                     max_tokens: int = 16384) -> Dict[str, np.ndarray]:
+    """Videollama3ImageProcessor.preprocess (:349-473) for a list of clips / images, each uint8 [t, H, W, 3] (an image
+    is a one-frame item, merge size 1 in the shipped processor: processing_cogreasoner.py:235-236).
     Returns pixel_values fp32 [N,588], grid_sizes int64 [V,3], merge_sizes int64 [V]."""
-    num_images = sum(int(v.shape[0]) for v in videos)
-    sizes = [(int(v.shape[1]), int(v.shape[2])) for v in videos]
-    targets = simple_batched_resize(sizes, num_images, PATCH * merge_size, min_tokens, max_tokens)
+    shapes = [(int(v.shape[0]), int(v.shape[1]), int(v.shape[2])) for v in items]
+    targets = media_target_sizes(shapes, list(merge_sizes), min_tokens, max_tokens)
     pix, grids = [], []
-    for v, (th, tw) in zip(videos, targets):
+    for v, ms, (th, tw) in zip(items, merge_sizes, targets):
         fr = np.stack([_resize_bicubic(f, (th, tw)) for f in v])                # [t, th, tw, 3] uint8
         x = pixel_value_table()[np.arange(3), fr]                               # [t, th, tw, 3] fp32
         x = x.transpose(0, 3, 1, 2)
-        pix.append(patchify(x, merge_size))
+        pix.append(patchify(x, ms))
         grids.append((v.shape[0], th // PATCH, tw // PATCH))
     return {
         "pixel_values": np.concatenate(pix, axis=0).astype(np.float32),
         "grid_sizes": np.asarray(grids, dtype=np.int64),
-        "merge_sizes": np.asarray([merge_size] * len(videos), dtype=np.int64),
+        "merge_sizes": np.asarray(list(merge_sizes), dtype=np.int64),
     }
+
+
+def preprocess_videos(videos: Sequence[np.ndarray], merge_size: int = 2, min_tokens: int = 16,
+                      max_tokens: int = 16384) -> Dict[str, np.ndarray]:
+    """preprocess_media for clips that all use one merge size"""
+    return preprocess_media(videos, [merge_size] * len(videos), min_tokens, max_tokens)
 
 
 def synthetic_clip(num_frames: int, height: int = 480, width: int = 854, kind: str = "noise",
@@ -262,17 +295,44 @@ def process_history_qas(conversation: List[Dict[str, Any]]) -> Tuple[List[str], 
     return qs[:-1], ans, (qs[-1] if qs else "")
 
 
+def _as_frames(x) -> Any:
+    """an image / clip as handed over by a caller -> uint8 [t, H, W, 3] (numpy, or a torch tensor left where it is)"""
+    import torch
+    if isinstance(x, torch.Tensor):
+        return x if x.ndim == 4 else x[None]
+    if isinstance(x, (list, tuple)):
+        x = np.stack([np.asarray(f) for f in x])
+    x = np.asarray(x)
+    return x if x.ndim == 4 else x[None]
+
+
 class CogStreamProcessor:
-    """Videollama3Qwen2Processor.__call__ for in-memory clips (processing_cogreasoner.py:732-744,665):
-    conversation items of type 'video' carry {'video': uint8 [t,H,W,3], 'timestamps': [...]}."""
+    """Videollama3Qwen2Processor (processing_cogreasoner.py:222-744) for in-memory media:
+
+        __call__(text=None, conversation=None, images=None, return_labels=False, **kwargs)             :732-744
+            conversation -> _process_conversation (:633-665): input_ids, attention_mask, pixel_values, grid_sizes,
+                            merge_sizes, modals, tokenizer, hist_qs, hist_as, current_question, all_timestamps,
+                            total_image_num, original_text
+            text         -> _process_plain (:667-694): input_ids, attention_mask (+ the image keys when images are given)
+        kwargs: add_system_prompt / add_generation_prompt (default False, the reference's chat_template_kwargs
+        defaults :213-217; the driver passes True, evaluate/answer_generate.py:62-67), return_tensors ("pt" only).
+
+    Conversation items: {"type": "video", "video": uint8 [t,H,W,3] | {"video_path": ..}, "timestamps": [...]},
+    {"type": "image", "image": uint8 [H,W,3], "timestamp": optional}, {"type": "text", "text": ...}. A video uses
+    video_merge_size (2), an image image_merge_size (1), as the shipped processor does (:235-236,:697-701).
+    `images=`: the media themselves in conversation order -- [("video", frames), ("image", img), ...] or bare arrays
+    (4-D = video) -- for callers that keep them out of the conversation, whose video items then carry "num_frames"
+    (and "timestamps"). In the reference this argument dies with a NameError (:639-641,655-665: all_timestamps / text
+    are unbound on that path); here it works. return_labels=True builds training targets (:520-608): training is
+    outside the inference path this package rebuilds, so it raises NotImplementedError."""
 
     def __init__(self, tokenizer, video_merge_size: int = 2, max_tokens: int = 16384, min_tokens: int = 16,
-                 device=None, pixel_dtype=None):
+                 device=None, pixel_dtype=None, image_merge_size: int = 1):
         """device=None: host PIL path (fp32 pixel_values on the CPU, as the reference returns them).
         device='cuda:N': frames are uploaded as bytes and pre-processed by the HIP kernels (same values bit for
         bit); pixel_values stay on the GPU in pixel_dtype (default bf16, the encoder's input dtype)."""
         self.tokenizer = tokenizer
-        self.video_merge_size = video_merge_size
+        self.video_merge_size, self.image_merge_size = video_merge_size, image_merge_size
         self.max_tokens, self.min_tokens = max_tokens, min_tokens
         self.device, self.pixel_dtype = device, pixel_dtype
         self.video_loader = None      # path -> video_io.DecodedVideo; default video_io.read_decoded_video (.npz)
@@ -289,12 +349,92 @@ class CogStreamProcessor:
             raise ValueError(f"{path}: pre-processing settings other than the reference's (patch 14, bicubic, "
                              "mean/std 0.5) are not implemented")
         return cls(tokenizer if tokenizer is not None else ck.load_tokenizer(path), video_merge_size=p["video_merge_size"], max_tokens=p["max_tokens"],
-                   min_tokens=p["min_tokens"], device=device, pixel_dtype=pixel_dtype)
+                   min_tokens=p["min_tokens"], device=device, pixel_dtype=pixel_dtype,
+                   image_merge_size=p.get("image_merge_size", 1))
 
-    def __call__(self, conversation: List[Dict[str, Any]], add_system_prompt: bool = True,
-                 add_generation_prompt: bool = True, return_tensors: str = "pt") -> Dict[str, Any]:
+    # ------------------------------------------------------------------ images
+    def process_images(self, images, merge_size=None) -> Dict[str, Any]:
+        """:689-705 -- images: [("video"|"image", data), ...] or bare arrays / tensors (4-D = video, 3-D = image)
+        -> pixel_values, grid_sizes, merge_sizes, modals"""
         import torch
+        named = []
+        if isinstance(images, tuple) and len(images) == 2 and isinstance(images[0], str):
+            images = [images]
+        elif not isinstance(images, (list, tuple)):
+            images = [images]
+        for it in images:
+            if isinstance(it, (list, tuple)) and len(it) == 2 and isinstance(it[0], str):
+                if it[0] not in ("image", "video"):
+                    raise ValueError(f"Could not make batched images from {it[0]!r}")
+                named.append((it[0], _as_frames(it[1])))
+            else:
+                fr = it if isinstance(it, torch.Tensor) else (np.stack([np.asarray(f) for f in it]) if isinstance(it, (list, tuple)) else np.asarray(it))
+                if fr.ndim not in (3, 4):
+                    raise ValueError(f"Could not make batched images from an array of shape {tuple(fr.shape)}")
+                named.append(("video" if fr.ndim == 4 else "image", _as_frames(fr)))
+        modals = [m for m, _ in named]
+        merges = ([self.image_merge_size if m == "image" else self.video_merge_size for m in modals] if merge_size is None
+                  else ([int(merge_size)] * len(named) if isinstance(merge_size, int) else [int(x) for x in merge_size]))
+        if len(merges) != len(named):
+            raise AssertionError("Merge size must be the same length as images.")
+        frames = [f for _, f in named]
+        if self.device is not None:
+            from .preprocess_gpu import preprocess_media_gpu
+            dev_items = [(v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v)))
+                         .to(self.device, non_blocking=True).contiguous() for v in frames]
+            feats = preprocess_media_gpu(dev_items, merges, self.min_tokens, self.max_tokens,
+                                         out_dtype=self.pixel_dtype or torch.bfloat16)
+        else:
+            host = preprocess_media([v.cpu().numpy() if isinstance(v, torch.Tensor) else v for v in frames], merges,
+                                    self.min_tokens, self.max_tokens)
+            feats = {k: torch.from_numpy(a) for k, a in host.items()}
+        feats["modals"] = modals
+        feats["_frames"] = frames
+        return feats
 
+    def process_text(self, text: str, image_inputs: Dict[str, Any]):
+        """:707-730 -- the i-th <image> becomes as many placeholders as image i has merged tokens -> (encoding, text)"""
+        per_image: List[int] = []
+        if image_inputs:
+            for (t, gh, gw), ms in zip(image_inputs["grid_sizes"].tolist(), image_inputs["merge_sizes"].tolist()):
+                per_image.extend([(gh // ms) * (gw // ms)] * t)
+        text = expand_image_tokens(text, per_image)
+        return self.tokenizer(text, return_tensors="pt"), text
+
+    # ------------------------------------------------------------------ entry points
+    def __call__(self, text: Optional[str] = None, conversation: Optional[List[Dict[str, Any]]] = None, images=None,
+                 return_labels: bool = False, **kwargs) -> Dict[str, Any]:
+        """:732-744"""
+        if conversation is not None:
+            if text is not None:
+                raise ValueError("You cannot provide 'message' with 'text'.")
+            return self._process_conversation(conversation, images, return_labels, **kwargs)
+        return self._process_plain(text, images, return_labels, **kwargs)
+
+    def _process_plain(self, text=None, images=None, return_labels: bool = False, **kwargs) -> Dict[str, Any]:
+        """:667-694 (the reference unpacks process_text's (encoding, text) pair as a mapping there and cannot return;
+        this is what it evidently means to return)"""
+        if text is None:
+            raise ValueError("You must provide 'text' or 'message'.")
+        if return_labels:
+            raise ValueError("return_labels is not supported for plain text processing.")
+        if kwargs.get("return_tensors", "pt") != "pt":
+            raise ValueError("only return_tensors='pt' is supported")
+        image_inputs = self.process_images(images, kwargs.get("merge_size")) if images is not None else {}
+        enc, _ = self.process_text(text, image_inputs)
+        image_inputs.pop("_frames", None)
+        return {"input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"], **image_inputs}
+
+    def _process_conversation(self, conversation, images=None, return_labels: bool = False, add_system_prompt: bool = False,
+                              add_generation_prompt: bool = False, return_tensors: str = "pt", **kwargs) -> Dict[str, Any]:
+        """:633-665"""
+        import torch
+        assert isinstance(conversation, list), "Conversation must be a list of messages."
+        if return_labels:
+            raise NotImplementedError("return_labels=True builds training targets (processing_cogreasoner.py:520-608); "
+                                      "training is outside the inference path of this package")
+        if return_tensors != "pt":
+            raise ValueError("only return_tensors='pt' is supported")
         # file-backed clips ({"video": {"video_path": ..., "fps": 1, "max_frames": 180}}, evaluate/answer_generate.py:126):
         # sampled at fps, cut to max_frames, timestamps stitched across segments -- _load_multimodal_data (:431-509)
         if any(isinstance(c, dict) and c.get("type") == "video" and isinstance(c.get("video"), dict)
@@ -304,7 +444,8 @@ class CogStreamProcessor:
                      for c in m["content"] if isinstance(c, dict) and c.get("type") == "video" and isinstance(c.get("video"), dict)}
             loader = self.video_loader or read_decoded_video
             conversation, _ = load_multimodal_data(conversation, {p: loader(p) for p in sorted(paths)})
-        videos, all_ts, conv = [], [], []
+        media, all_ts, conv = [], [], []      # _gather_multimodal_data (:511-530) + the template's view of each item
+        given = list(images) if images is not None else None
         for msg in conversation:
             if isinstance(msg["content"], str):
                 conv.append(msg)
@@ -312,49 +453,55 @@ class CogStreamProcessor:
             items = []
             for c in msg["content"]:
                 if isinstance(c, dict) and c.get("type") == "video":
-                    v = c["video"] if isinstance(c["video"], torch.Tensor) else np.asarray(c["video"])
+                    if given is not None:
+                        v = _as_frames(given[len(media)][1] if isinstance(given[len(media)], (list, tuple)) and
+                                       isinstance(given[len(media)][0], str) else given[len(media)])
+                    else:
+                        v = _as_frames(c["video"])
                     ts = [float(t) for t in c.get("timestamps", range(len(v)))]
-                    videos.append(v)
+                    media.append(("video", v))
                     all_ts.extend(ts)
                     items.append({"type": "video", "num_frames": len(v), "timestamps": ts})
+                elif isinstance(c, dict) and c.get("type") == "image":
+                    if given is not None:
+                        im = given[len(media)][1] if isinstance(given[len(media)], (list, tuple)) and isinstance(given[len(media)][0], str) else given[len(media)]
+                    else:
+                        im = c["image"]
+                    media.append(("image", _as_frames(im)))
+                    item = {"type": "image"}
+                    if "timestamp" in c:
+                        item["timestamp"] = c["timestamp"]
+                        all_ts.append(float(c["timestamp"]))
+                    items.append(item)
                 else:
                     items.append(c)
             conv.append({"role": msg["role"], "content": items})
-        feats = None
-        if videos and self.device is not None:
-            from .preprocess_gpu import preprocess_videos_gpu
-            dev_videos = [(v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v)))
-                          .to(self.device, non_blocking=True).contiguous() for v in videos]
-            feats = preprocess_videos_gpu(dev_videos, self.video_merge_size, self.min_tokens, self.max_tokens,
-                                          out_dtype=self.pixel_dtype or torch.bfloat16)
-        elif videos:
-            host = preprocess_videos([v.cpu().numpy() if isinstance(v, torch.Tensor) else v for v in videos],
-                                     self.video_merge_size, self.min_tokens, self.max_tokens)
-            feats = {k: torch.from_numpy(a) for k, a in host.items()}
+        if given is not None and len(given) != len(media):
+            raise AssertionError("Number of images does not match the number of image tokens in the text.")
+        feats = self.process_images(media) if media else {}
+        frames = feats.pop("_frames", [])
         text = render_conversation(conv, add_system_prompt, add_generation_prompt)
-        per_image: List[int] = []
-        if feats is not None:
-            for (t, gh, gw), ms in zip(feats["grid_sizes"].tolist(), feats["merge_sizes"].tolist()):
-                per_image.extend([(gh // ms) * (gw // ms)] * t)
-        text = expand_image_tokens(text, per_image)
-        enc = self.tokenizer(text, return_tensors="pt")
+        enc, text = self.process_text(text, feats)
         hist_qs, hist_as, cur_q = process_history_qas(conversation)
-        # content keys of the video segments (xxh64 of the raw frame bytes) for the model's visual-token cache
+        # content keys of the media (xxh64 of the raw bytes) for the model's visual-token cache
         import xxhash
         video_keys = [xxhash.xxh64(memoryview(np.ascontiguousarray(v.cpu().numpy() if isinstance(v, torch.Tensor) else v))
-                                   .cast("B")).hexdigest() for v in videos]   # hashed in place: no copy of the frames
+                                   .cast("B")).hexdigest() for v in frames]   # hashed in place: no copy of the frames
+        total_image_num = sum(int(v.shape[0]) for v in frames)     # :656-658
         out = {
             "video_keys": video_keys,
             "input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"],
-            "modals": ["video"] * len(videos), "tokenizer": self.tokenizer,
+            "modals": feats.get("modals", []), "tokenizer": self.tokenizer,
             "hist_qs": hist_qs, "hist_as": hist_as, "current_question": cur_q,
-            "all_timestamps": all_ts, "total_image_num": len(all_ts), "original_text": text,
+            "all_timestamps": all_ts, "total_image_num": total_image_num, "original_text": text,
         }
-        if feats is not None:
-            out["pixel_values"] = feats["pixel_values"]
-            out["grid_sizes"] = feats["grid_sizes"]
-            out["merge_sizes"] = feats["merge_sizes"]
+        for k in ("pixel_values", "grid_sizes", "merge_sizes"):
+            if k in feats:
+                out[k] = feats[k]
         return out
 
-    def batch_decode(self, ids, **kw):
-        return self.tokenizer.batch_decode(ids, **kw)
+    def batch_decode(self, *args, **kwargs):
+        return self.tokenizer.batch_decode(*args, **kwargs)
+
+    def decode(self, *args, **kwargs):
+        return self.tokenizer.decode(*args, **kwargs)

@@ -122,6 +122,67 @@ def golden_preprocess():
          ramp_grid=lut_out["grid_sizes"])
 
 
+def golden_image_modality():
+    """the IMAGE modality (merge_size 1) through the reference's own objects:
+      * Videollama3ImageProcessor.preprocess on two images (merge 1 for all: simple_batched_resize with factor 14,
+        image_processing_videollama3.py:424-431) and on [video clip, image] with merge sizes [2, 1] (batched_resize,
+        :432-439): pixel_values, grid_sizes;
+      * the reference encoder on an image + a clip in one call, merge sizes [1, 2], one frame per call (the shipped
+        flash semantics) and its eager global form;
+      * _get_compression_mask's image branch (cogreasoner_chat.py:400-403): all True for an image."""
+    import transformers.image_utils as _iu
+    import transformers.video_utils as _vu
+    if not hasattr(_iu, "VideoInput"):
+        _iu.VideoInput = _vu.VideoInput
+    from model.image_processing_videollama3 import Videollama3ImageProcessor
+    from cogstream_amd.processing import synthetic_clip
+    with open("/root/reference/model/preprocessor_config.json") as f:
+        pc = json.load(f)
+    proc = Videollama3ImageProcessor(**{k: pc[k] for k in ("do_resize", "resample", "do_rescale", "rescale_factor",
+                                                           "do_normalize", "image_mean", "image_std", "do_convert_rgb",
+                                                           "min_tokens", "max_tokens", "patch_size")})
+    img_a = synthetic_clip(1, 75, 110, kind="noise", clip_idx=11)[0][0]
+    img_b = synthetic_clip(1, 130, 64, kind="drift", clip_idx=12)[0][0]
+    clip = synthetic_clip(3, 60, 100, kind="drift", clip_idx=13)[0]
+    two = proc.preprocess(images=[img_a, img_b], merge_size=[1, 1], return_tensors="np")
+    mixed = proc.preprocess(images=[[f for f in clip], img_b], merge_size=[2, 1], return_tensors="np")
+    # a budget small enough to shrink the mixed batch (batched_resize's total_tokens > max_tokens branch)
+    proc_small = Videollama3ImageProcessor(**{**{k: pc[k] for k in ("do_resize", "resample", "do_rescale", "rescale_factor",
+                                                                    "do_normalize", "image_mean", "image_std", "do_convert_rgb",
+                                                                    "min_tokens", "patch_size")}, "max_tokens": 40})
+    mixed_small = proc_small.preprocess(images=[[f for f in clip], img_b], merge_size=[2, 1], return_tensors="np")
+    out = {"image_args": np.array([[75, 110, 11], [130, 64, 12]]), "clip_args": np.array([3, 60, 100, 13]),
+           "two_pixel_values": two["pixel_values"].astype(np.float32), "two_grid": two["grid_sizes"], "two_merge": two["merge_sizes"],
+           "mixed_pixel_values": mixed["pixel_values"].astype(np.float32), "mixed_grid": mixed["grid_sizes"],
+           "mixed_merge": mixed["merge_sizes"], "mixed_small_pixel_values": mixed_small["pixel_values"].astype(np.float32),
+           "mixed_small_grid": mixed_small["grid_sizes"]}
+    # encoder: one image (merge 1) + one 2-frame clip (merge 2)
+    cfg = VisionConfig(**VIT)
+    st = random_vit_state(cfg, seed=3, std=0.05)
+    m = ref_vit(st, cfg)
+    g = torch.Generator().manual_seed(23)
+    grid = torch.tensor([[1, 3, 5], [2, 4, 4]])
+    merge = torch.tensor([1, 2])
+    pix = torch.rand(int(grid.prod(1).sum()), 588, generator=g) * 2 - 1
+    with torch.no_grad():
+        eager_global = m(pix, grid, merge)
+        outs, row = [], 0
+        for (t, h, w), ms in zip(grid.tolist(), merge.tolist()):
+            for _ in range(t):
+                outs.append(m(pix[row:row + h * w], torch.tensor([[1, h, w]]), torch.tensor([ms])))
+                row += h * w
+        block_diag = torch.cat(outs, 0)
+    out.update(vit_pixel_values=pix, vit_grid=grid, vit_merge=merge, vit_eager_global=eager_global, vit_block_diag=block_diag,
+               vit_checksum=np.float64(checksum(st)))
+    # compression mask with an image among the inputs
+    ns = types.SimpleNamespace()
+    batched = grid.prod(dim=1).div(merge ** 2).long()
+    mask = ref_chat.Videollama3MetaForCausalLM._get_compression_mask(ns, pix, batched, grid, merge, ["image", "video"],
+                                                                     minor_frame_indices=[])
+    out["mask_image_video"] = mask
+    save("image_modality.npz", **out)
+
+
 def golden_kmeans():
     cases = {}
     for ci, (T, P, D, K, seed) in enumerate([(150, 3, 16, 10, 0), (64, 2, 8, 5, 1), (40, 1, 32, 6, 2), (6, 2, 4, 8, 3)]):
@@ -920,7 +981,7 @@ if __name__ == "__main__":
     if "--only-preprocess" in sys.argv:
         golden_preprocess()
         sys.exit(0)
-    which = sys.argv[1:] or ["preprocess", "vit", "vit_bf16", "kmeans", "kmeans_reseed", "compress", "text", "e2e", "e2e_blockdiag", "qwen2", "lora"]
+    which = sys.argv[1:] or ["preprocess", "vit", "vit_bf16", "kmeans", "kmeans_reseed", "compress", "text", "e2e", "e2e_blockdiag", "qwen2", "lora", "image_modality"]
     with torch.no_grad():
         for w in which:
             globals()["golden_" + w]()

@@ -96,7 +96,7 @@ def test_processor_call_contract():
     from toy_tokenizer import IMAGE, ToyTokenizer
     frames, ts = pr.synthetic_clip(4, 56, 56)
     conv = [{"role": "user", "content": [{"type": "video", "video": frames, "timestamps": ts}, {"type": "text", "text": "What?"}]}]
-    out = pr.CogStreamProcessor(ToyTokenizer())(conversation=conv)
+    out = pr.CogStreamProcessor(ToyTokenizer())(conversation=conv, add_system_prompt=True, add_generation_prompt=True)
     for k in ("input_ids", "attention_mask", "pixel_values", "grid_sizes", "merge_sizes", "modals", "tokenizer", "hist_qs",
               "hist_as", "current_question", "all_timestamps", "total_image_num", "original_text"):
         assert k in out, k

@@ -198,7 +198,8 @@ def test_processor_from_pretrained_on_the_reference_directory():
     assert (proc.max_tokens, proc.min_tokens, proc.video_merge_size) == (16384, 16, 2)
     frames, ts = synthetic_clip(8, 224, 224)
     out = proc(conversation=[{"role": "user", "content": [{"type": "video", "video": frames, "timestamps": ts},
-                                                          {"type": "text", "text": "What is happening in the video?"}]}])
+                                                          {"type": "text", "text": "What is happening in the video?"}]}],
+               add_system_prompt=True, add_generation_prompt=True)
     assert out["input_ids"].shape == (1, 621) and int((out["input_ids"] == 151665).sum()) == 512
     with pytest.raises(FileNotFoundError, match="git-LFS"):
         ck.Checkpoint("/root/reference/model")

@@ -126,7 +126,7 @@ def test_cfg2_full_pipeline_with_real_token_ids(dev, model7b):
         frames[i, 160:320, 8 * i:8 * i + 160] = base[1, 160:320, :160]
     conv = [{"role": "user", "content": [{"type": "video", "video": frames, "timestamps": ts},
                                          {"type": "text", "text": "What is happening in the video?"}]}]
-    inputs = pr.CogStreamProcessor(tok, device=dev)(conversation=conv)
+    inputs = pr.CogStreamProcessor(tok, device=dev)(conversation=conv, add_system_prompt=True, add_generation_prompt=True)
     assert inputs["input_ids"].shape == (1, 15395) and inputs["grid_sizes"].tolist() == [[64, 22, 42]]
     assert int((inputs["input_ids"] == 151665).sum()) == 64 * 231 == 14784
     sel = model.qa_selection(**inputs, mode="FCC")
@@ -162,7 +162,7 @@ def test_cfg3_event_selection_reaches_kmeans_at_full_size(dev, model7b):
     clip = np.concatenate([pr.synthetic_clip(64, kind="drift", clip_idx=c)[0] for c in range(4)])
     conv = [{"role": "user", "content": [{"type": "video", "video": clip, "timestamps": [float(i) for i in range(256)]},
                                          {"type": "text", "text": "What is happening in the video?"}]}]
-    inputs = pr.CogStreamProcessor(tok, device=dev)(conversation=conv)
+    inputs = pr.CogStreamProcessor(tok, device=dev)(conversation=conv, add_system_prompt=True, add_generation_prompt=True)
     assert inputs["grid_sizes"].tolist() == [[256, 10, 20]] and inputs["total_image_num"] == 256
     random.seed(3)
     torch.manual_seed(3)

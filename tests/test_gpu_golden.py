@@ -608,3 +608,46 @@ def test_back_to_back_encodes_with_different_grids_do_not_race(dev):
         alone_a = enc(pa, ga, ma, attn_mode=mode)
         torch.cuda.synchronize()
         assert torch.equal(a, alone_a) and torch.equal(a2, alone_a) and torch.equal(b, alone_b)
+
+
+def test_image_modality_vs_reference(dev):
+    """tests/golden/image_modality.npz on the HIP path: GPU pre-processing of images (merge size 1) and of an image next
+    to a clip (batched_resize) bit-equal to the reference processor's pixel_values; the encoder on an image + a clip in
+    ONE call (merge sizes [1, 2]) in both attention modes; the compression mask keeps every token of an image"""
+    from cogstream_amd import processing as pr
+    from cogstream_amd.preprocess_gpu import preprocess_media_gpu
+    from cogstream_amd.vision import BLOCK_DIAG, REF_EAGER_GLOBAL, VisionEncoder
+    from cogstream_amd.weights import VisionConfig, random_vit_state
+    g = _load("image_modality.npz")
+    imgs = [pr.synthetic_clip(1, int(a[0]), int(a[1]), kind=k, clip_idx=int(a[2]))[0] for a, k in zip(g["image_args"], ["noise", "drift"])]
+    ca = g["clip_args"]
+    clip = pr.synthetic_clip(int(ca[0]), int(ca[1]), int(ca[2]), kind="drift", clip_idx=int(ca[3]))[0]
+    for tag, items, merges, kw in (("two", imgs, [1, 1], {}), ("mixed", [clip, imgs[1]], [2, 1], {}),
+                                   ("mixed_small", [clip, imgs[1]], [2, 1], {"max_tokens": 40})):
+        out = preprocess_media_gpu([torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in items], merges,
+                                   out_dtype=torch.float32, **kw)
+        assert out["grid_sizes"].tolist() == g[f"{tag}_grid"].tolist() and out["merge_sizes"].tolist() == merges
+        assert torch.equal(out["pixel_values"].cpu(), torch.from_numpy(g[f"{tag}_pixel_values"])), tag
+    cfg = VisionConfig(**VIT)
+    pix, grid, merge = torch.from_numpy(g["vit_pixel_values"]).to(dev), torch.from_numpy(g["vit_grid"]), torch.from_numpy(g["vit_merge"])
+    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 3e-2)):
+        enc = VisionEncoder(random_vit_state(cfg, seed=3, std=0.05), cfg, dtype=dtype, device=dev)
+        bd = enc(pix.to(dtype), grid, merge, attn_mode=BLOCK_DIAG)
+        eg = enc(pix.to(dtype), grid, merge, attn_mode=REF_EAGER_GLOBAL)
+        assert bd.shape == (23, 576)
+        assert rel_err(bd.float(), torch.from_numpy(g["vit_block_diag"])) < tol
+        assert rel_err(eg.float(), torch.from_numpy(g["vit_eager_global"])) < tol
+    model = _tiny_model(dev, torch.float32, 0)
+    batched = grid.prod(dim=1).div(merge ** 2).long()
+    m = model._get_compression_mask(pix, batched, grid, merge, ["image", "video"], minor_frame_indices=[])
+    assert torch.equal(m.cpu(), torch.from_numpy(g["mask_image_video"]))
+    # processor -> generate with an image in the conversation (merge size 1 through the whole product path)
+    from toy_tokenizer import ToyTokenizer
+    proc = pr.CogStreamProcessor(ToyTokenizer(), device=dev, pixel_dtype=torch.float32)
+    conv = [{"role": "user", "content": [{"type": "image", "image": imgs[0]}, {"type": "text", "text": "What is this?"}]}]
+    inputs = proc(conversation=conv, add_system_prompt=True, add_generation_prompt=True)
+    assert inputs["modals"] == ["image"] and inputs["merge_sizes"].tolist() == [1] and inputs["total_image_num"] == 1
+    inputs = model.qa_selection(**inputs, mode="FCC")
+    ids, _ = model.generate(**inputs, max_new_tokens=4)
+    assert ids.shape[0] == 1 and 1 <= ids.shape[1] <= 4
+    assert bool(model.last_debug["compression_mask"].all())        # an image keeps all its tokens

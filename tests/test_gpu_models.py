@@ -198,8 +198,8 @@ def test_processor_gpu_path_equals_host_path(dev):
     frames, ts = pr.synthetic_clip(3, 120, 214, kind="drift", clip_idx=2)
     conv = [{"role": "user", "content": [{"type": "video", "video": frames, "timestamps": ts},
                                          {"type": "text", "text": "what moves?"}]}]
-    host = pr.CogStreamProcessor(tok)(conv)
-    gpu = pr.CogStreamProcessor(tok, device=dev)(conv)
+    host = pr.CogStreamProcessor(tok)(conversation=conv, add_system_prompt=True, add_generation_prompt=True)
+    gpu = pr.CogStreamProcessor(tok, device=dev)(conversation=conv, add_system_prompt=True, add_generation_prompt=True)
     assert gpu["pixel_values"].is_cuda and gpu["pixel_values"].dtype == torch.bfloat16
     assert torch.equal(gpu["pixel_values"].cpu(), host["pixel_values"].bfloat16())
     assert torch.equal(gpu["grid_sizes"], host["grid_sizes"]) and torch.equal(gpu["input_ids"], host["input_ids"])

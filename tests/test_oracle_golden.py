@@ -251,3 +251,85 @@ def test_qwen2_oracle_matches_reference(tag):
     h16, _ = oq.forward(lst16, emb.bfloat16(), **kw)
     ref16, ref32 = torch.from_numpy(g[f"{tag}_hidden_bf16"]), torch.from_numpy(g[f"{tag}_hidden_f32"])
     assert rel_err(h16.float(), ref16) <= 1.0 * rel_err(ref16, ref32)
+
+
+def test_image_modality_preprocessing_encoder_and_mask_vs_reference():
+    """tests/golden/image_modality.npz (made by the reference's Videollama3ImageProcessor, its encoder and
+    _get_compression_mask): images use merge size 1; two images share simple_batched_resize, an image next to a clip goes
+    through batched_resize (over and under the token budget); the oracle encoder handles merge sizes [1, 2] in one
+    call; an image keeps every token in the compression mask (cogreasoner_chat.py:400-403)"""
+    from cogstream_amd import processing as pr
+    from cogstream_amd.weights import VisionConfig, random_vit_state
+    from oracle import compress as oc
+    from oracle import vision as ov
+    g = np.load(os.path.join(G, "image_modality.npz"))
+    imgs = [pr.synthetic_clip(1, int(a[0]), int(a[1]), kind=k, clip_idx=int(a[2]))[0] for a, k in zip(g["image_args"], ["noise", "drift"])]
+    ca = g["clip_args"]
+    clip = pr.synthetic_clip(int(ca[0]), int(ca[1]), int(ca[2]), kind="drift", clip_idx=int(ca[3]))[0]
+    for tag, items, merges, kw in (("two", imgs, [1, 1], {}), ("mixed", [clip, imgs[1]], [2, 1], {}),
+                                   ("mixed_small", [clip, imgs[1]], [2, 1], {"max_tokens": 40})):
+        out = pr.preprocess_media(items, merges, **kw)
+        assert out["grid_sizes"].tolist() == g[f"{tag}_grid"].tolist(), tag
+        assert np.array_equal(out["pixel_values"], g[f"{tag}_pixel_values"]), tag
+    cfg = VisionConfig(hidden_size=576, intermediate_size=200, num_hidden_layers=2, num_attention_heads=8)
+    st = random_vit_state(cfg, seed=3, std=0.05)
+    assert abs(float(sum(v.double().abs().sum() for v in st.values())) - float(g["vit_checksum"])) < 1e-6
+    pix, grid, merge = torch.from_numpy(g["vit_pixel_values"]), torch.from_numpy(g["vit_grid"]), torch.from_numpy(g["vit_merge"])
+    for mode, key in ((0, "vit_block_diag"), (1, "vit_eager_global")):
+        tok = ov.encode(st, pix, grid, merge, heads=8, layers=2, mode=mode)
+        assert tok.shape == (15 + 8, 576) and rel_err(tok, torch.from_numpy(g[key])) < 2e-5
+    batched = grid.prod(dim=1).div(merge ** 2).long()
+    mask = oc.compression_mask(pix, grid, merge, ["image", "video"], minor_frame_indices=[])
+    assert torch.equal(mask, torch.from_numpy(g["mask_image_video"])) and bool(mask[:15].all()) and int(batched[0]) == 15
+
+
+def test_processor_call_surface_matches_the_reference():
+    """Videollama3Qwen2Processor.__call__(text=None, conversation=None, images=None, return_labels=False, **kwargs)
+    (processing_cogreasoner.py:732-744): argument order, the two error messages, chat-template defaults (no system
+    turn, no generation prompt unless asked), the plain-text path, image items (merge 1, 'Time x.xs: <image>\\n'),
+    media handed over through images= (the path that dies with a NameError in the reference, :639-641)"""
+    import inspect
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from toy_tokenizer import ToyTokenizer
+    from cogstream_amd import processing as pr
+    from cogstream_amd.processing_cogreasoner import Videollama3Qwen2Processor
+    proc = Videollama3Qwen2Processor(ToyTokenizer())
+    assert list(inspect.signature(proc.__call__).parameters)[:4] == ["text", "conversation", "images", "return_labels"]
+    with pytest.raises(ValueError, match="You cannot provide 'message' with 'text'."):
+        proc(text="x", conversation=[{"role": "user", "content": "q"}])
+    with pytest.raises(ValueError, match="You must provide 'text' or 'message'."):
+        proc()
+    with pytest.raises(ValueError, match="return_labels is not supported for plain text processing."):
+        proc(text="x", return_labels=True)
+    with pytest.raises(NotImplementedError):
+        proc(conversation=[{"role": "user", "content": "q"}], return_labels=True)
+    # chat-template defaults of the reference: nothing added unless asked for
+    out = proc(conversation=[{"role": "user", "content": "q?"}])
+    assert out["original_text"] == "<|im_start|>user\nq?<|im_end|>\n" and out["modals"] == [] and "pixel_values" not in out
+    out = proc(conversation=[{"role": "user", "content": "q?"}], add_system_prompt=True, add_generation_prompt=True)
+    assert out["original_text"].startswith("<|im_start|>system\n" + pr.DEFAULT_SYSTEM) and out["original_text"].endswith("<|im_start|>assistant\n")
+    # image + clip in one conversation
+    img = pr.synthetic_clip(1, 75, 110, kind="noise", clip_idx=11)[0][0]
+    clip, ts = pr.synthetic_clip(3, 60, 100, kind="drift", clip_idx=13)
+    conv = [{"role": "user", "content": [{"type": "image", "image": img, "timestamp": 2.04}, {"type": "video", "video": clip, "timestamps": ts},
+                                         {"type": "text", "text": "What changed?"}]}]
+    out = proc(conversation=conv, add_generation_prompt=True)
+    assert out["modals"] == ["image", "video"] and out["merge_sizes"].tolist() == [1, 2] and out["total_image_num"] == 4
+    gh, gw = out["grid_sizes"][0, 1:].tolist()
+    per = [gh * gw] + [int(g[1] * g[2]) // 4 for g in out["grid_sizes"][1:].tolist() for _ in range(3)]
+    assert out["original_text"].startswith("<|im_start|>user\nTime 2.0s: " + "<image>" * per[0] + "\nTime 0.0s:" + "<image>" * per[1] + ",")
+    assert int((out["input_ids"] == 258).sum()) == sum(per) and out["all_timestamps"] == [2.04, 0.0, 1.0, 2.0]
+    assert out["pixel_values"].shape[0] == gh * gw + 3 * int(out["grid_sizes"][1, 1] * out["grid_sizes"][1, 2])
+    # the same media through images= (named and bare), conversation items then only describe them
+    conv2 = [{"role": "user", "content": [{"type": "image", "timestamp": 2.04}, {"type": "video", "num_frames": 3, "timestamps": ts},
+                                          {"type": "text", "text": "What changed?"}]}]
+    for given in ([("image", img), ("video", clip)], [img, clip]):
+        o2 = proc(conversation=conv2, images=given, add_generation_prompt=True)
+        assert torch.equal(o2["input_ids"], out["input_ids"]) and torch.equal(o2["pixel_values"], out["pixel_values"])
+        assert o2["video_keys"] == out["video_keys"]
+    # plain text + images (process_text expands the placeholders): what _process_plain means to return
+    plain = proc(text="look: <image> and <image>", images=[img, img])
+    assert set(plain) == {"input_ids", "attention_mask", "pixel_values", "grid_sizes", "merge_sizes", "modals"}
+    assert int((plain["input_ids"] == 258).sum()) == 2 * gh * gw and plain["modals"] == ["image", "image"]
+    assert set(proc(text="no media")) == {"input_ids", "attention_mask"}

@@ -108,6 +108,6 @@ def test_live_real_tokenizer_agrees_with_the_record():
     frames, ts = pr.synthetic_clip(8, 224, 224)
     conv = [{"role": "user", "content": [{"type": "video", "video": frames, "timestamps": ts},
                                          {"type": "text", "text": "What is happening in the video?"}]}]
-    out = pr.CogStreamProcessor(real)(conversation=conv)
+    out = pr.CogStreamProcessor(real)(conversation=conv, add_system_prompt=True, add_generation_prompt=True)
     assert out["input_ids"].shape[1] == rec.data["prompts"][1]["len"] == 621
     assert out["input_ids"][0].tolist() == unrle(rec.data["prompts"][1]["ids_rle"])
