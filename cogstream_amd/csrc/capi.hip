@@ -297,6 +297,20 @@ cogs_status cogs_kmeans_pp_step(cogs_stream stream, int dtype, const void* feats
     if (!feats || !nearest2 || T <= 0) return COGS_E_INVALID;
     return cogs_k_kmeans_pp_step((hipStream_t)stream, dtype, feats, T, PD, row, first, nearest2, probs_host, (float*)ws, ns);
 }
+cogs_status cogs_kmeans_pp(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD, int K, const float* q_draws,
+                           int32_t* idx, int32_t* zero_flag, float* nearest2, void* ws, size_t ws_bytes) {
+    int ns = 0;
+    const size_t need = cogs_k_kmeans_ws(T, PD, 1, &ns);
+    if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
+    if (!feats || !q_draws || !idx || !zero_flag || !nearest2 || T <= 0 || K <= 0) return COGS_E_INVALID;
+    return cogs_k_kmeans_pp((hipStream_t)stream, dtype, feats, T, PD, K, q_draws, idx, zero_flag, nearest2, (float*)ws, ns);
+}
+cogs_status cogs_kmeans_margins(cogs_stream stream, int T, int64_t PD, int K, void* ws, size_t ws_bytes, float* min_margin,
+                                int32_t* rows_below) {
+    const size_t need = cogs_k_kmeans_ws(T, PD, K, nullptr);
+    if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
+    return cogs_k_kmeans_margins((hipStream_t)stream, T, PD, K, (float*)ws, min_margin, rows_below);
+}
 cogs_status cogs_kmeans_lloyd(cogs_stream stream, int dtype, const void* feats, const float* ts, int T, int64_t PD, int K,
                               float alpha, int max_iter, float tol, const int32_t* reseed_pool, int pool_len,
                               float* centres, float* centre_ts, int64_t* assign, int* iterations, int* reseeds_used,
@@ -410,12 +424,14 @@ static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* p
                                     void* out_tokens, void* ws, size_t ws_bytes);
 
 // Frames are independent under block-diagonal attention (per-frame attention, RoPE and 2x2 merge:
-// modeling_videollama3_encoder.py:309-312,427,487-501). A SMALL clip -- one rank's share of a frame-sharded clip -- has
-// too few GEMM tiles per launch to fill 256 CUs (8 frames of 22 x 42 patches: 145 tiles for the N = 1152 shapes), so it
-// is encoded as two halves on two streams: the second half's kernels take the CUs the first half's ragged rounds leave
-// idle. Same arithmetic per row, bit-identical tokens (tests/test_gpu_models.py). Not while the per-kernel profiler is
-// on (overlapping launches stretch every bracket) and not for large clips, whose launches fill the chip on their own.
-static const int64_t VIT_SPLIT_MAX_PATCHES = 32768;
+// modeling_videollama3_encoder.py:309-312,427,487-501), so a clip is encoded as two halves on two streams: the second
+// half's kernels take the CUs the first half's ragged last rounds leave idle (every persistent GEMM launch ends in a
+// partly filled round of tiles). Same arithmetic per row, bit-identical tokens (tests/test_gpu_models.py). One rank's
+// share of a frame-sharded clip (8 frames of 22 x 42 patches: 145 tiles for the N = 1152 shapes) gains 10 %, the whole
+// 64-frame clip 2.7 % (round 4, same box, interleaved: 60.8 -> 59.2 ms; 256 frames at 140 x 280: 47.3 -> 46.5 ms).
+// Not while the per-kernel profiler is on: overlapping launches stretch every bracket, so bench.py's `roofline` and
+// `breakdown_ms` describe the kernels one at a time. COGS_VIT_STREAMS=1 or COGS_VIT_SPLIT_MAX=<patches> switch it off.
+static const int64_t VIT_SPLIT_MAX_PATCHES = (int64_t)1 << 40;
 
 cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
                             const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,

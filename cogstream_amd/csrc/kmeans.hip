@@ -28,6 +28,20 @@
 
 namespace {
 
+// control words of the in-library Lloyd loop (device ints, in the workspace). The host queues SEVERAL iterations between
+// two reads; every kernel of an iteration returns at once when the loop has ended (converged / pool exhausted), so the
+// speculatively queued ones change nothing.
+enum { CTL_USED = 0,      // reseed-pool entries consumed so far
+       CTL_ABORT = 1,     // an iteration wanted more reseeds than the pool holds: it was not committed, the loop stops
+       CTL_EMPTY = 2,     // empty clusters of the last iteration
+       CTL_SHIFT = 3,     // centre shift of the last committed iteration (float bits)
+       CTL_DONE = 4,      // shift <= tol: converged
+       CTL_ITERS = 5,     // iterations committed
+       CTL_MARGIN = 6,    // min over rows and iterations of (second-best - best) / best final distance (float bits, >= 0)
+       CTL_NEAR = 7,      // rows (summed over iterations) whose margin is below NEAR_TIE
+       CTL_WORDS = 8 };
+constexpr float NEAR_TIE = 1e-3f;   // below this the reference's own sgemm rounding decides a row
+
 constexpr int SL = 512;       // columns per slice
 constexpr int KMAX = 32;      // centres per sqdist launch (K itself is unbounded: 18 for 256 frames, 40 for 600)
 constexpr int UB = 2048;      // columns per update workgroup (256 threads x 8)
@@ -64,9 +78,10 @@ template <typename T>
 __global__ __launch_bounds__(256, 4) void sqdist_kernel(const T* __restrict__ x, int Tn, long PD,
                                                         const float* __restrict__ centres,
                                                         const int* __restrict__ centre_rows, int centre_row, int K, int k0,
-                                                        int Ktot, float* __restrict__ partial) {
+                                                        int Ktot, float* __restrict__ partial, const int* __restrict__ ctl) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* cs = reinterpret_cast<float*>(smem_raw);
+    if (ctl && (ctl[CTL_ABORT] | ctl[CTL_DONE])) return;   // speculatively queued iteration behind the last one
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const long j0 = (long)blockIdx.x * SL;
     const int KB = (K + 3) & ~3;
@@ -111,9 +126,9 @@ __global__ __launch_bounds__(256, 4) void sqdist_kernel(const T* __restrict__ x,
     };
     load_rows(r_lo + wid);
     for (int t = r_lo + wid; t < r_hi; t += 8) {
-        float xa[8], xb[8];
+        f32x2 xab[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { xa[e] = xn[0][e]; xb[e] = xn[1][e]; }
+        for (int e = 0; e < 8; ++e) xab[e] = f32x2{xn[0][e], xn[1][e]};
         if (t + 8 < r_hi) load_rows(t + 8);
         const bool live_b = t + 4 < r_hi;
         float* pa = partial + ((long)blockIdx.x * Tn + t) * Ktot + k0 + kperm;
@@ -125,18 +140,19 @@ __global__ __launch_bounds__(256, 4) void sqdist_kernel(const T* __restrict__ x,
             for (int q = 0; q < 4; ++q) {
                 const f32x4 c0 = *reinterpret_cast<const f32x4*>(cl + (m + q) * SL);
                 const f32x4 c1 = *reinterpret_cast<const f32x4*>(cl + (m + q) * SL + 256);
-                float sa = 0.f, sb = 0.f;
+                // the two rows ride in the two halves of a register pair: v_pk_add_f32 / v_pk_fma_f32 do both rows'
+                // subtraction and fma in one instruction each. Every accumulator still sees its own products in the same
+                // order (column e of the first half, then of the second), so the sums are bit-identical to the scalar form
+                f32x2 s = {0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d0 = xa[e] - c0[e], d1 = xa[4 + e] - c1[e];
-                    const float g0 = xb[e] - c0[e], g1 = xb[4 + e] - c1[e];
-                    sa = fmaf(d0, d0, sa);
-                    sb = fmaf(g0, g0, sb);
-                    sa = fmaf(d1, d1, sa);
-                    sb = fmaf(g1, g1, sb);
+                    const f32x2 d0 = xab[e] - f32x2{c0[e], c0[e]};
+                    const f32x2 d1 = xab[4 + e] - f32x2{c1[e], c1[e]};
+                    s = __builtin_elementwise_fma(d0, d0, s);
+                    s = __builtin_elementwise_fma(d1, d1, s);
                 }
-                a[q] = sa;
-                b[q] = sb;
+                a[q] = s[0];
+                b[q] = s[1];
             }
             // transposing butterfly of one unit: 4 values x 64 lanes -> every 16-lane row holds the wave total of ONE
             // centre: row 0 -> m, row 1 -> m + 2, row 2 -> m + 1, row 3 -> m + 3
@@ -192,9 +208,10 @@ __device__ __forceinline__ void reduce_row(const float* __restrict__ partial, in
 __global__ __launch_bounds__(256) void reduce_assign_kernel(const float* __restrict__ partial, int nslices, int Tn, int K,
                                                             const float* __restrict__ ts, const float* __restrict__ cts,
                                                             float alpha, float* __restrict__ dist2_out,
-                                                            int64_t* __restrict__ assign) {
+                                                            int64_t* __restrict__ assign, int* __restrict__ ctl) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* scratch = reinterpret_cast<double*>(smem_raw);           // 256 doubles
+    if (ctl && (ctl[CTL_ABORT] | ctl[CTL_DONE])) return;
     float* d2s = reinterpret_cast<float*>(scratch + 256);            // [K]
     const int t = blockIdx.x;
     reduce_row(partial, nslices, Tn, K, t, d2s, scratch);
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(256) void reduce_assign_kernel(const float* __restr
     }
     fmin_ = wave_min(fmin_); fmax_ = wave_max(fmax_);
     tmin_ = wave_min(tmin_); tmax_ = wave_max(tmax_);
-    float best = INFINITY;
+    float best = INFINITY, second = INFINITY;
     int bk = 0x7fffffff;
     for (int k = lane; k < K; k += 64) {
         const float df = sqrtf(d2s[k]);
@@ -222,7 +239,8 @@ __global__ __launch_bounds__(256) void reduce_assign_kernel(const float* __restr
         const float nf = fmax_ > fmin_ ? __fdiv_rn(__fsub_rn(df, fmin_), __fsub_rn(fmax_, fmin_)) : 0.f;
         const float nt = tmax_ > tmin_ ? __fdiv_rn(__fsub_rn(dt, tmin_), __fsub_rn(tmax_, tmin_)) : 0.f;
         const float fd = sqrtf(__fadd_rn(__fmul_rn(nf, nf), __fmul_rn(alpha, __fmul_rn(nt, nt))));
-        if (fd < best) { best = fd; bk = k; }     // ascending k per lane: the lane keeps its FIRST minimum
+        if (fd < best) { second = best; best = fd; bk = k; }     // ascending k per lane: the lane keeps its FIRST minimum
+        else if (fd < second) second = fd;
     }
     const float wbest = wave_min(best);
     // first minimum overall = smallest k among the lanes that hold the minimum value
@@ -230,6 +248,69 @@ __global__ __launch_bounds__(256) void reduce_assign_kernel(const float* __restr
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
     if (lane == 0) assign[t] = cand == 0x7fffffff ? 0 : cand;        // all-NaN row: cluster 0, like a serial first-minimum scan
+    if (ctl) {
+        // how close the decision was: runner-up = the smallest final distance of any OTHER cluster
+        const float wsecond = wave_min(bk == cand ? second : best);
+        if (lane == 0 && K > 1) {
+            float m = (wsecond - wbest) / wbest;                      // 0 / 0 (two zero distances) counts as a tie
+            if (!(m == m) || m < 0.f) m = 0.f;
+            atomicMin(reinterpret_cast<unsigned*>(ctl + CTL_MARGIN), __float_as_uint(m));   // non-negative floats order like their bits
+            if (m < NEAR_TIE) atomicAdd(ctl + CTL_NEAR, 1);
+        }
+    }
+}
+
+// k-means++ draw (:53-60) on the device: probs = (sqrt(nearest2))^2 as the reference computes them from cdist's distances,
+// normalised by their sum; torch.multinomial(probs, 1) on the CPU IS argmax(probs / q), q ~ Exponential(1) one draw per
+// element from the CPU generator (ATen multinomial, n_sample == 1) -- the host hands those draws over. A zero sum (every
+// row coincides with a chosen centre) is the reference's random.randint branch: flagged, the host then takes the step-wise
+// path. One workgroup; the sum runs in fp64 in a fixed order (torch's own fp32 summation order is not reproduced: the sum
+// is a common divisor of all ratios and only moves the argmax between ratios closer than a few ulps).
+__global__ __launch_bounds__(256) void kpp_select_kernel(const float* __restrict__ nearest2, const float* __restrict__ q, int Tn,
+                                                         int* __restrict__ idx_out, int* __restrict__ zero_flag) {
+    __shared__ double red[4];
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double sum = 0.0;
+    for (int t = tid; t < Tn; t += 256) {
+        const float d = sqrtf(nearest2[t]);
+        sum += (double)__fmul_rn(d, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    const float total = (float)((red[0] + red[1]) + (red[2] + red[3]));
+    if (total == 0.f) {
+        if (tid == 0) { *zero_flag = 1; *idx_out = 0; }
+        return;
+    }
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int t = tid; t < Tn; t += 256) {                 // ascending t per thread: the first maximum is kept
+        const float d = sqrtf(nearest2[t]);
+        const float r = __fdiv_rn(__fdiv_rn(__fmul_rn(d, d), total), q[t]);
+        if (r > best || (r != r && best == best)) { best = r; bi = t; }      // NaN counts as the maximum, like torch.argmax
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const bool take = (ob > best) || (ob != ob && best == best) || ((ob == best || (ob != ob && best != best)) && oi < bi);
+        if (take) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { rv[wid] = best; ri[wid] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float b = rv[0]; int i = ri[0];
+        for (int w = 1; w < 4; ++w) {
+            const float ob = rv[w]; const int oi = ri[w];
+            const bool take = (ob > b) || (ob != ob && b == b) || ((ob == b || (ob != ob && b != b)) && oi < i);
+            if (take) { b = ob; i = oi; }
+        }
+        *idx_out = i == 0x7fffffff ? 0 : i;
+    }
 }
 
 // k-means++ step (:46-60): nearest2[t] = min(nearest2[t], dist2 to the newest centre) (first: plain store)
@@ -264,6 +345,7 @@ __global__ __launch_bounds__(1024) void members_kernel(const int64_t* __restrict
     int* a = reinterpret_cast<int*>(smem_raw);        // [Tn]
     int* cnt = a + Tn;                                // [K + 1]
     const int tid = threadIdx.x, nt = blockDim.x;
+    if (ctl && (ctl[CTL_ABORT] | ctl[CTL_DONE])) return;
     for (int k = tid; k <= K; k += nt) cnt[k] = 0;
     __syncthreads();
     for (int t = tid; t < Tn; t += nt) {
@@ -275,7 +357,7 @@ __global__ __launch_bounds__(1024) void members_kernel(const int64_t* __restrict
     __syncthreads();
     if (tid == 0) {
         int o = 0, ne = 0;
-        const int used = ctl ? ctl[0] : 0;
+        const int used = ctl ? ctl[CTL_USED] : 0;
         offs[0] = 0;
         for (int k = 0; k < K; ++k) {
             const int n = cnt[k];
@@ -290,10 +372,10 @@ __global__ __launch_bounds__(1024) void members_kernel(const int64_t* __restrict
             offs[k + 1] = o;
         }
         if (ctl) {
-            ctl[2] = ne;
+            ctl[CTL_EMPTY] = ne;
             if (!reseed_in && ne > 0) {
-                if (!pool || used + ne > pool_len) ctl[1] = 1;      // abort: this iteration must not commit
-                else ctl[0] = used + ne;
+                if (!pool || used + ne > pool_len) ctl[CTL_ABORT] = 1;      // abort: this iteration must not commit
+                else ctl[CTL_USED] = used + ne;
             }
         }
     }
@@ -337,7 +419,7 @@ __global__ __launch_bounds__(256) void update_kernel(const T* __restrict__ x, lo
                                                      const int* __restrict__ reseed_rows, const int* __restrict__ ctl,
                                                      float* __restrict__ centres, float* __restrict__ shift_partial) {
     __shared__ float red[4];
-    if (ctl && ctl[1]) return;                     // pool exhausted: nothing of this iteration is committed
+    if (ctl && (ctl[CTL_ABORT] | ctl[CTL_DONE])) return;   // pool exhausted: nothing of this iteration is committed; or the loop has ended
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int k = blockIdx.y;
     const long col = ((long)blockIdx.x * 256 + tid) * 8;
@@ -386,14 +468,15 @@ __global__ __launch_bounds__(256) void update_kernel(const T* __restrict__ x, lo
 // status (nullable, host-mapped): {shift, reseeds used, abort, empty clusters} for the Lloyd loop's one read per iteration
 __global__ __launch_bounds__(256) void update_final_kernel(const float* __restrict__ ts, int K,
                                                            const int* __restrict__ offs, const int* __restrict__ members,
-                                                           const int* __restrict__ reseed_rows, const int* __restrict__ ctl,
+                                                           const int* __restrict__ reseed_rows, int* __restrict__ ctl,
                                                            float* __restrict__ cts,
                                                            const float* __restrict__ shift_partial, int nblk,
                                                            float* __restrict__ scratch, float* __restrict__ shift_out,
-                                                           volatile int* __restrict__ status, int Tn_lds) {
+                                                           volatile int* __restrict__ status, int Tn_lds, float tol) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* mts = reinterpret_cast<float*>(smem_raw);      // [Tn] time stamps in member order (0 floats when Tn_lds == 0)
-    const bool aborted = ctl && ctl[1];
+    if (ctl && ctl[CTL_DONE]) return;                     // a speculatively queued iteration behind the converged one
+    const bool aborted = ctl && ctl[CTL_ABORT];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (!aborted) {
         if (Tn_lds > 0) {
@@ -427,11 +510,15 @@ __global__ __launch_bounds__(256) void update_final_kernel(const float* __restri
             total = f + sqrtf(tt);
             shift_out[0] = total;
         }
-        if (status) {
-            status[0] = __builtin_bit_cast(int, total);
-            status[1] = ctl ? ctl[0] : 0;
-            status[2] = aborted ? 1 : 0;
-            status[3] = ctl ? ctl[2] : 0;
+        if (ctl && !aborted) {
+            ctl[CTL_SHIFT] = __builtin_bit_cast(int, total);
+            ctl[CTL_ITERS] += 1;
+            if (total <= tol) ctl[CTL_DONE] = 1;
+        }
+        if (status) {      // host-mapped copy of the control words (one read per batch of iterations)
+#pragma unroll
+            for (int i = 0; i < CTL_WORDS; ++i) status[i] = ctl ? ctl[i] : 0;
+            __threadfence_system();
         }
     }
 }
@@ -536,7 +623,7 @@ int cogs_k_select_near(hipStream_t st, const float* dist2, const int64_t* assign
 
 // ---- workspace: [A] max(sqdist slice partials [ns][T][K], update shift partials [nblk][K]) floats, then the member
 // lists (offs [K+1], members [T]), the update scratch [2K], and the Lloyd loop's own state: dist2 [T][K] floats,
-// reseed rows [K], ctl [4], reseed pool [POOL_MAX] ints
+// reseed rows [K], ctl [CTL_WORDS], reseed pool [POOL_MAX] ints
 constexpr int POOL_MAX = 4096;
 static size_t ws_floats(int T, long PD, int K, int ns) {
     const size_t a = (size_t)ns * T * K;
@@ -546,7 +633,7 @@ static size_t ws_floats(int T, long PD, int K, int ns) {
 size_t cogs_k_kmeans_ws(int T, long PD, int K, int* nslices) {
     const int ns = (int)((PD + SL - 1) / SL);
     if (nslices) *nslices = ns;
-    return (ws_floats(T, PD, K, ns) + (size_t)(K + 1) + (size_t)T + 2 * (size_t)K + (size_t)T * K + (size_t)K + 4 + POOL_MAX) * 4;
+    return (ws_floats(T, PD, K, ns) + (size_t)(K + 1) + (size_t)T + 2 * (size_t)K + (size_t)T * K + (size_t)K + CTL_WORDS + POOL_MAX) * 4;
 }
 namespace {
 struct KmWs {
@@ -563,13 +650,13 @@ KmWs carve(float* ws, int T, long PD, int K) {
     w.dist2 = w.scratch + 2 * K;
     w.reseed = (int*)(w.dist2 + (size_t)T * K);
     w.ctl = w.reseed + K;
-    w.pool = w.ctl + 4;
+    w.pool = w.ctl + CTL_WORDS;
     return w;
 }
 
 template <typename T>
 void launch_sqdist(hipStream_t st, const void* feats, int Tn, long PD, const float* centres, const int* centre_rows,
-                   int centre_row, int kb, int k0, int K, float* partial, int nslices) {
+                   int centre_row, int kb, int k0, int K, float* partial, int nslices, const int* ctl) {
     static std::atomic<uint64_t> done{0};
     cogs_ensure_dyn_lds((const void*)sqdist_kernel<T>, KMAX * SL * 4, done);
     const int kp = (kb + 3) & ~3;
@@ -583,23 +670,23 @@ void launch_sqdist(hipStream_t st, const void* feats, int Tn, long PD, const flo
     rg = rg < 1 ? 1 : (rg > 8 ? 8 : rg);
     while (rg > 1 && (Tn + rg - 1) / rg < 16) --rg;
     hipLaunchKernelGGL((sqdist_kernel<T>), dim3(nslices, rg), dim3(256), (size_t)kp * SL * 4, st, (const T*)feats, Tn, PD,
-                       centres, centre_rows, centre_row, kb, k0, K, partial);
+                       centres, centre_rows, centre_row, kb, k0, K, partial, ctl);
 }
 int sqdist_partials(hipStream_t st, int dtype, const void* feats, int T, long PD, const float* centres,
-                    const int* centre_rows, int centre_row, int K, float* partial, int nslices) {
+                    const int* centre_rows, int centre_row, int K, float* partial, int nslices, const int* ctl = nullptr) {
     if (K <= 0 || T <= 0 || PD % 8) return COGS_E_INVALID;
     if (nslices != (int)((PD + SL - 1) / SL)) return COGS_E_WORKSPACE;
     for (int k0 = 0; k0 < K; k0 += KMAX) {          // the LDS centre slice holds KMAX clusters at a time
         const int kb = K - k0 < KMAX ? K - k0 : KMAX;
-        if (dtype == COGS_DT_BF16) launch_sqdist<bf16_t>(st, feats, T, PD, centres, centre_rows, centre_row, kb, k0, K, partial, nslices);
-        else launch_sqdist<float>(st, feats, T, PD, centres, centre_rows, centre_row, kb, k0, K, partial, nslices);
+        if (dtype == COGS_DT_BF16) launch_sqdist<bf16_t>(st, feats, T, PD, centres, centre_rows, centre_row, kb, k0, K, partial, nslices, ctl);
+        else launch_sqdist<float>(st, feats, T, PD, centres, centre_rows, centre_row, kb, k0, K, partial, nslices, ctl);
     }
     return COGS_LAUNCH_CHECK();
 }
 int launch_reduce_assign(hipStream_t st, const float* partial, int nslices, int T, int K, const float* ts, const float* cts,
-                         float alpha, float* dist2, int64_t* assign) {
+                         float alpha, float* dist2, int64_t* assign, int* ctl = nullptr) {
     if (K > 4096) return COGS_E_UNSUPPORTED;
-    hipLaunchKernelGGL(reduce_assign_kernel, dim3(T), dim3(256), (size_t)256 * 8 + (size_t)K * 4, st, partial, nslices, T, K, ts, cts, alpha, dist2, assign);
+    hipLaunchKernelGGL(reduce_assign_kernel, dim3(T), dim3(256), (size_t)256 * 8 + (size_t)K * 4, st, partial, nslices, T, K, ts, cts, alpha, dist2, assign, ctl);
     return COGS_LAUNCH_CHECK();
 }
 int launch_members(hipStream_t st, const int64_t* assign, int T, int K, const KmWs& w, const int* pool, int pool_len,
@@ -616,7 +703,7 @@ int launch_members(hipStream_t st, const int64_t* assign, int T, int K, const Km
     return COGS_LAUNCH_CHECK();
 }
 int launch_update(hipStream_t st, int dtype, const void* feats, const float* ts, int T, long PD, int K, const KmWs& w,
-                  const int* ctl, float* centres, float* centre_ts, float* shift_out, volatile int* status) {
+                  int* ctl, float* centres, float* centre_ts, float* shift_out, volatile int* status, float tol = -1.f) {
     const int nblk = cogs_k_kmeans_update_blocks(PD);
     if (dtype == COGS_DT_BF16)
         hipLaunchKernelGGL(update_kernel<bf16_t>, dim3(nblk, K), dim3(256), 0, st, (const bf16_t*)feats, PD, K, w.offs, w.members,
@@ -626,7 +713,7 @@ int launch_update(hipStream_t st, int dtype, const void* feats, const float* ts,
                            w.reseed, ctl, centres, w.partial);
     const int t_lds = T <= MEMB_T ? T : 0;       // member-ordered time stamps staged in LDS (64 KiB at most)
     hipLaunchKernelGGL(update_final_kernel, dim3(1), dim3(256), (size_t)t_lds * 4, st, ts, K, w.offs, w.members, w.reseed, ctl,
-                       centre_ts, w.partial, nblk, w.scratch, shift_out, status, t_lds);
+                       centre_ts, w.partial, nblk, w.scratch, shift_out, status, t_lds, tol);
     return COGS_LAUNCH_CHECK();
 }
 }  // namespace
@@ -677,53 +764,103 @@ int cogs_k_kmeans_pp_step(hipStream_t st, int dtype, const void* feats, int T, l
     return COGS_OK;
 }
 
-// The Lloyd loop (kmeans_with_time.py:71-131) with ONE host read per iteration (the centre shift and the reseed
-// bookkeeping, written by update_final into host-mapped memory). Empty clusters take their rows from `pool`, the
-// host's pre-drawn random.randint values, in the reference's order; if an iteration needs more than the pool holds it
-// is not committed and the call returns with *exhausted = 1 (the caller draws more and calls again).
+// The whole k-means++ seeding (kmeans_with_time.py:41-62) in one call, no host round trip per centre: step m measures
+// every row against the newest centre (row idx[m-1], read from device memory), folds it into nearest2 and draws centre m
+// as argmax(probs / q[m-1]) (kpp_select_kernel). q: device fp32 [K-1][T], the Exponential(1) draws the reference's K-1
+// torch.multinomial calls would make on the CPU generator, made ahead by the host. idx: device int32 [K], idx[0] given.
+// *zero_flag (device int, zeroed here) is set when a step found all probabilities zero -- the reference's
+// random.randint branch; the indices from that step on are then meaningless and the caller redoes the seeding step by step.
+int cogs_k_kmeans_pp(hipStream_t st, int dtype, const void* feats, int T, long PD, int K, const float* q, int* idx,
+                     int* zero_flag, float* nearest2, float* ws, int nslices) {
+    if (T <= 0 || K <= 0 || PD % 8 || !q || !idx || !zero_flag || !nearest2) return COGS_E_INVALID;
+    const KmWs w = carve(ws, T, PD, 1);
+    if (hipMemsetAsync(zero_flag, 0, sizeof(int), st) != hipSuccess) return COGS_E_HIP;
+    for (int m = 1; m < K; ++m) {
+        const int rc = sqdist_partials(st, dtype, feats, T, PD, nullptr, idx + (m - 1), -1, 1, w.partial, nslices);
+        if (rc != COGS_OK) return rc;
+        hipLaunchKernelGGL(reduce_min_kernel, dim3((T + 3) / 4), dim3(256), 0, st, w.partial, nslices, T, m == 1 ? 1 : 0, nearest2);
+        hipLaunchKernelGGL(kpp_select_kernel, dim3(1), dim3(256), 0, st, nearest2, q + (size_t)(m - 1) * T, T, idx + m, zero_flag);
+    }
+    return COGS_LAUNCH_CHECK();
+}
+
+// The Lloyd loop (kmeans_with_time.py:71-131). The host queues up to LLOYD_BATCH iterations between two reads of the
+// control words (update_final copies them into host-mapped memory): every kernel of an iteration returns at once when an
+// earlier one has converged or run the reseed pool dry, so the iterations queued behind the last one change nothing.
+// Empty clusters take their rows from `pool`, the host's pre-drawn random.randint values, in the reference's order; if an
+// iteration needs more than the pool holds it is not committed and the call returns with *exhausted = 1 (the caller
+// draws more and calls again with the remaining budget).
+constexpr int LLOYD_BATCH = 4;
+namespace {
+struct StatusBlock { volatile int* h = nullptr; int* d = nullptr; int dev = -1; };
+// one host-mapped block per calling thread; replaced (and the old one freed) when the thread's device changes
+bool status_block(StatusBlock& b) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (b.h && b.dev == dev) return true;
+    if (b.h) { (void)hipHostFree((void*)b.h); b.h = nullptr; b.d = nullptr; }
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) return false;
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipHostFree(hp); return false; }
+    b.h = (volatile int*)hp; b.d = (int*)dp; b.dev = dev;
+    return true;
+}
+}  // namespace
+
 int cogs_k_kmeans_lloyd(hipStream_t st, int dtype, const void* feats, const float* ts, int T, long PD, int K, float alpha,
                         int max_iter, float tol, const int* pool_host, int pool_len, float* centres, float* centre_ts,
                         int64_t* assign, int* iterations, int* reseeds_used, int* exhausted, float* ws, int nslices) {
     if (T <= 0 || K <= 0 || PD % 8 || max_iter < 0 || pool_len < 0 || pool_len > POOL_MAX) return COGS_E_INVALID;
-    if (T > MEMB_T || (size_t)(T + K + 1) * 4 > 64 * 1024 || K > 4096) return COGS_E_UNSUPPORTED;
-    static thread_local volatile int* status_h = nullptr;
-    static thread_local int* status_d = nullptr;
-    static thread_local int status_dev = -1;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!status_h || status_dev != dev) {
-        void* hp = nullptr;
-        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) return COGS_E_HIP;
-        void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) return COGS_E_HIP;
-        status_h = (volatile int*)hp; status_d = (int*)dp; status_dev = dev;
-    }
+    if (T > MEMB_T || (size_t)(T + K + 1) * 4 > 64 * 1024 || K > 4096) return COGS_E_UNSUPPORTED;   // T + K + 1 <= 16 384
+    static thread_local StatusBlock sb;
+    if (!status_block(sb)) return COGS_E_HIP;
     if (iterations) *iterations = 0;
     if (reseeds_used) *reseeds_used = 0;
     if (exhausted) *exhausted = 0;
-    if (max_iter == 0) return COGS_OK;             // nothing to do (and nothing queued that would still read pool_host)
+    if (max_iter == 0) return COGS_OK;             // nothing to do
     const KmWs w = carve(ws, T, PD, K);
-    if (hipMemsetAsync(w.ctl, 0, 16, st) != hipSuccess) return COGS_E_HIP;
-    if (pool_len > 0 && hipMemcpyAsync(w.pool, pool_host, (size_t)pool_len * 4, hipMemcpyHostToDevice, st) != hipSuccess) return COGS_E_HIP;
-    float* shift_d = (float*)(w.ctl + 3);         // ctl[3] doubles as the device copy of the shift
-    int it = 0, used = 0, ex = 0;
-    for (; it < max_iter; ++it) {
-        int rc = sqdist_partials(st, dtype, feats, T, PD, centres, nullptr, -1, K, w.partial, nslices);
-        if (rc != COGS_OK) return rc;
-        rc = launch_reduce_assign(st, w.partial, nslices, T, K, ts, centre_ts, alpha, nullptr, assign);
-        if (rc != COGS_OK) return rc;
-        rc = launch_members(st, assign, T, K, w, w.pool, pool_len, nullptr, w.ctl);
-        if (rc != COGS_OK) return rc;
-        rc = launch_update(st, dtype, feats, ts, T, PD, K, w, w.ctl, centres, centre_ts, shift_d, (volatile int*)status_d);
-        if (rc != COGS_OK) return rc;
+    {   // control words: zero, margin = +inf
+        int init[CTL_WORDS] = {0, 0, 0, 0, 0, 0, 0x7f800000, 0};
+        // (both copies are synchronous with respect to the host buffers: at most 16 KiB, and the caller may free pool_host
+        // right after an error return)
+        if (hipMemcpy(w.ctl, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) return COGS_E_HIP;
+        if (pool_len > 0 && hipMemcpy(w.pool, pool_host, (size_t)pool_len * 4, hipMemcpyHostToDevice) != hipSuccess) return COGS_E_HIP;
+    }
+    int queued = 0, it = 0, used = 0, ex = 0;
+    int rc = COGS_OK;
+    while (queued < max_iter) {
+        const int batch = max_iter - queued < LLOYD_BATCH ? max_iter - queued : LLOYD_BATCH;
+        for (int b = 0; b < batch && rc == COGS_OK; ++b) {
+            rc = sqdist_partials(st, dtype, feats, T, PD, centres, nullptr, -1, K, w.partial, nslices, w.ctl);
+            if (rc == COGS_OK) rc = launch_reduce_assign(st, w.partial, nslices, T, K, ts, centre_ts, alpha, nullptr, assign, w.ctl);
+            if (rc == COGS_OK) rc = launch_members(st, assign, T, K, w, w.pool, pool_len, nullptr, w.ctl);
+            if (rc == COGS_OK) rc = launch_update(st, dtype, feats, ts, T, PD, K, w, w.ctl, centres, centre_ts, (float*)(w.ctl + CTL_SHIFT),
+                                                  (volatile int*)sb.d, tol);
+        }
+        queued += batch;
         if (hipStreamSynchronize(st) != hipSuccess) return COGS_E_HIP;
-        const int s0 = status_h[0];
-        used = status_h[1];
-        if (status_h[2]) { ex = 1; break; }      // not committed
-        if (__builtin_bit_cast(float, s0) <= tol) { ++it; break; }
+        if (rc != COGS_OK) return rc;
+        it = sb.h[CTL_ITERS];
+        used = sb.h[CTL_USED];
+        if (sb.h[CTL_ABORT]) { ex = 1; break; }      // the aborted iteration was not committed
+        if (sb.h[CTL_DONE]) break;
     }
     if (iterations) *iterations = it;
     if (reseeds_used) *reseeds_used = used;
     if (exhausted) *exhausted = ex;
+    return COGS_OK;
+}
+
+// how close the assignments of the last cogs_k_kmeans_lloyd call on this workspace were: the smallest relative margin
+// (second-best - best) / best of the final distance over all rows and iterations, and the number of (row, iteration)
+// pairs below 1e-3 -- below that the reference's own cdist rounding decides the row
+int cogs_k_kmeans_margins(hipStream_t st, int T, long PD, int K, float* ws, float* min_margin, int* rows_below) {
+    const KmWs w = carve(ws, T, PD, K);
+    int h[CTL_WORDS];
+    if (hipMemcpyAsync(h, w.ctl, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return COGS_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return COGS_E_HIP;
+    if (min_margin) *min_margin = __builtin_bit_cast(float, h[CTL_MARGIN]);
+    if (rows_below) *rows_below = h[CTL_NEAR];
     return COGS_OK;
 }

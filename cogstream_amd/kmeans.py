@@ -17,15 +17,10 @@ import torch
 
 from . import ops
 
-last_stats = {"kpp_passes": 0, "iterations": 0}    # of the most recent call (bench.py: bytes moved per stage)
-_pinned = {}                                        # T -> pinned host fp32 [T] (page-locking costs ~0.1 ms: done once)
-
-
-def _pinned_probs(T: int) -> torch.Tensor:
-    buf = _pinned.get(T)
-    if buf is None:
-        buf = _pinned[T] = torch.empty(T, dtype=torch.float32).pin_memory()
-    return buf
+last_stats = {"kpp_passes": 0, "iterations": 0, "kpp_path": "", "min_rel_margin": float("inf"), "rows_below_1e-3": 0}
+"""of the most recent call (bench.py: bytes moved per stage; DESIGN.md section 2: how close the assignments were).
+min_rel_margin = smallest (second-best - best) / best final distance over all rows and Lloyd iterations; rows_below_1e-3
+= (row, iteration) pairs under 1e-3, where the reference's own cdist rounding decides a row."""
 
 
 def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int, alpha: float = 2,
@@ -42,19 +37,36 @@ def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int
     K, PD = cluster_num, P * D
     ws = ops.kmeans_workspace(T, PD, K, dev)
 
-    # ---- k-means++ on feature distance only (:41-62): one device step + one pinned read of the [T] distances per
-    # centre; the draw itself is the reference's torch.multinomial on the CPU generator ----
-    idx: List[int] = [random.randint(0, T - 1)]
-    nearest2 = torch.empty(T, dtype=torch.float32, device=dev)
-    probs = _pinned_probs(T)
-    while len(idx) < K:
-        ops.kmeans_pp_step(x, idx[-1], len(idx) == 1, nearest2, probs, ws)     # (sqrt(d2))**2 of the reference
-        s = probs.sum()
-        if s.item() == 0:
-            new = random.randint(0, T - 1)
-        else:
-            new = int(torch.multinomial(probs / s, 1).item())        # CPU generator, like the reference
-        idx.append(new)
+    # ---- k-means++ on feature distance only (:41-62). The reference draws centre m with torch.multinomial(probs, 1) on
+    # the CPU generator, which IS argmax(probs / q) with q = empty_like(probs).exponential_(1) (ATen, n_sample == 1). The
+    # K - 1 rows of q are drawn here, exactly as those calls would consume the generator, and the whole seeding runs in
+    # one library call (cogs_kmeans_pp) with no host round trip per centre. If a step finds all probabilities zero --
+    # the reference then calls random.randint instead of multinomial -- both generators are put back and the seeding is
+    # redone step by step (the round-3 path: one pinned read of the [T] distances per centre) ----
+    first = random.randint(0, T - 1)
+    py_state, torch_state = random.getstate(), torch.get_rng_state()
+    q = torch.stack([torch.empty(T, dtype=torch.float32).exponential_(1) for _ in range(K - 1)])
+    idx_d, flag = ops.kmeans_pp(x, first, K, q.to(dev, non_blocking=True), ws)
+    got = torch.cat([idx_d, flag]).cpu().tolist()
+    if got[-1] == 0:
+        idx: List[int] = got[:K]
+        last_stats["kpp_path"] = "one call"
+    else:
+        random.setstate(py_state)
+        torch.set_rng_state(torch_state)
+        idx = [first]
+        nearest2 = torch.empty(T, dtype=torch.float32, device=dev)
+        probs = torch.empty(T, dtype=torch.float32).pin_memory()
+        while len(idx) < K:
+            ops.kmeans_pp_step(x, idx[-1], len(idx) == 1, nearest2, probs, ws)
+            probs.sqrt_().square_()                        # the reference's (cdist distance) ** 2 (:53)
+            s = probs.sum()
+            if s.item() == 0:
+                new = random.randint(0, T - 1)
+            else:
+                new = int(torch.multinomial(probs / s, 1).item())        # CPU generator, like the reference
+            idx.append(new)
+        last_stats["kpp_path"] = "step by step (a zero-probability step)"
 
     rows = torch.tensor(idx, dtype=torch.int64, device=dev)
     centres = ops.pack_rows(x.index_select(0, rows), torch.float32, PD) if x.dtype != torch.float32 \
@@ -84,6 +96,7 @@ def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int
     for _ in range(used_total):
         random.randint(0, T - 1)
     last_stats["kpp_passes"], last_stats["iterations"] = K - 1, done
+    last_stats["min_rel_margin"], last_stats["rows_below_1e-3"] = ops.kmeans_margins(T, PD, K, ws)
     return centres.view(K, P, D), centre_ts, assign
 
 

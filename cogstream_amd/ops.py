@@ -236,6 +236,29 @@ def kmeans_pp_step(feats, row: int, first: bool, nearest2: torch.Tensor, probs_h
                                     ptr(nearest2), ptr(probs_host), ptr(ws), ws.numel()), "cogs_kmeans_pp_step")
 
 
+def kmeans_pp(feats, first_row: int, K: int, q_draws: torch.Tensor, ws):
+    """cogs_kmeans_pp -> (centre rows int32 [K] on the device, zero-sum flag int32 [1] on the device). q_draws: device
+    fp32 [K-1, T] Exponential(1) draws of the CPU generator"""
+    T, PD = feats.shape
+    assert q_draws.is_cuda and q_draws.dtype == torch.float32 and q_draws.shape == (K - 1, T) and q_draws.is_contiguous()
+    idx = torch.empty(K, device=feats.device, dtype=torch.int32)
+    idx[0] = int(first_row)
+    flag = torch.empty(1, device=feats.device, dtype=torch.int32)
+    nearest2 = torch.empty(T, device=feats.device, dtype=torch.float32)
+    check(L.lib.cogs_kmeans_pp(current_stream(), dtype_code(feats.dtype), ptr(feats), T, PD, int(K), ptr(q_draws), ptr(idx),
+                               ptr(flag), ptr(nearest2), ptr(ws), ws.numel()), "cogs_kmeans_pp")
+    return idx, flag
+
+
+def kmeans_margins(T: int, PD: int, K: int, ws):
+    """cogs_kmeans_margins -> (min relative margin of the final distances, (row, iteration) pairs below 1e-3) of the last
+    kmeans_lloyd call on `ws`"""
+    m, n = C.c_float(0), C.c_int32(0)
+    check(L.lib.cogs_kmeans_margins(current_stream(), int(T), int(PD), int(K), ptr(ws), ws.numel(), C.byref(m), C.byref(n)),
+          "cogs_kmeans_margins")
+    return float(m.value), int(n.value)
+
+
 def kmeans_lloyd(feats, ts, centres, centre_ts, assign, alpha: float, max_iter: int, tol: float, pool, ws):
     """cogs_kmeans_lloyd -> (iterations completed, reseeds used, pool exhausted). pool: python list of pre-drawn rows"""
     T, PD = feats.shape
