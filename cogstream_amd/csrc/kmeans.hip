@@ -37,7 +37,7 @@ enum { CTL_USED = 0,      // reseed-pool entries consumed so far
        CTL_SHIFT = 3,     // centre shift of the last committed iteration (float bits)
        CTL_DONE = 4,      // shift <= tol: converged
        CTL_ITERS = 5,     // iterations committed
-       CTL_MARGIN = 6,    // min over rows and iterations of (second-best - best) / best final distance (float bits, >= 0)
+       CTL_MARGIN = 6,    // min over rows and iterations of the decision margin (reduce_assign_kernel; float bits, >= 0)
        CTL_NEAR = 7,      // rows (summed over iterations) whose margin is below NEAR_TIE
        CTL_WORDS = 8 };
 constexpr float NEAR_TIE = 1e-3f;   // below this the reference's own sgemm rounding decides a row
@@ -232,15 +232,19 @@ __global__ __launch_bounds__(256) void reduce_assign_kernel(const float* __restr
     fmin_ = wave_min(fmin_); fmax_ = wave_max(fmax_);
     tmin_ = wave_min(tmin_); tmax_ = wave_max(tmax_);
     float best = INFINITY, second = INFINITY;
-    int bk = 0x7fffffff;
-    for (int k = lane; k < K; k += 64) {
-        const float df = sqrtf(d2s[k]);
+    int bk = 0x7fffffff, sk = 0x7fffffff;
+    auto final_dist = [&](int k, float& df, float& nf) {
+        df = sqrtf(d2s[k]);
         const float dt = fabsf(tt - cts[k]);
-        const float nf = fmax_ > fmin_ ? __fdiv_rn(__fsub_rn(df, fmin_), __fsub_rn(fmax_, fmin_)) : 0.f;
+        nf = fmax_ > fmin_ ? __fdiv_rn(__fsub_rn(df, fmin_), __fsub_rn(fmax_, fmin_)) : 0.f;
         const float nt = tmax_ > tmin_ ? __fdiv_rn(__fsub_rn(dt, tmin_), __fsub_rn(tmax_, tmin_)) : 0.f;
-        const float fd = sqrtf(__fadd_rn(__fmul_rn(nf, nf), __fmul_rn(alpha, __fmul_rn(nt, nt))));
-        if (fd < best) { second = best; best = fd; bk = k; }     // ascending k per lane: the lane keeps its FIRST minimum
-        else if (fd < second) second = fd;
+        return sqrtf(__fadd_rn(__fmul_rn(nf, nf), __fmul_rn(alpha, __fmul_rn(nt, nt))));
+    };
+    for (int k = lane; k < K; k += 64) {
+        float df, nf;
+        const float fd = final_dist(k, df, nf);
+        if (fd < best) { second = best; sk = bk; best = fd; bk = k; }     // ascending k per lane: the lane keeps its FIRST minimum
+        else if (fd < second) { second = fd; sk = k; }
     }
     const float wbest = wave_min(best);
     // first minimum overall = smallest k among the lanes that hold the minimum value
@@ -248,11 +252,29 @@ __global__ __launch_bounds__(256) void reduce_assign_kernel(const float* __restr
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
     if (lane == 0) assign[t] = cand == 0x7fffffff ? 0 : cand;        // all-NaN row: cluster 0, like a serial first-minimum scan
-    if (ctl) {
-        // how close the decision was: runner-up = the smallest final distance of any OTHER cluster
-        const float wsecond = wave_min(bk == cand ? second : best);
-        if (lane == 0 && K > 1) {
-            float m = (wsecond - wbest) / wbest;                      // 0 / 0 (two zero distances) counts as a tie
+    if (ctl && K > 1 && cand != 0x7fffffff) {
+        // How close was the decision? Runner-up = the smallest final distance of any OTHER cluster. The margin is
+        // expressed in the unit the near-tie study uses: the RELATIVE change of the feature
+        // distances that would flip the order. A relative change e of d_k moves nf_k by d_k e / R (R = max - min of
+        // the row) and the final distance sqrt(nf^2 + alpha nt^2) by (nf_k / fd_k) d_k e / R; with the winner moving up
+        // and the runner-up down the gap closes at e* = gap / (s_1 + s_2); reported as 2 e*, which for a pure feature
+        // decision (all time terms equal) is (d_2 - d_1) / mean(d_1, d_2), the study's margin. A decision the feature
+        // distances cannot flip (s_1 = s_2 = 0) reports +inf.
+        const float oval = bk == cand ? second : best;
+        const int okk = bk == cand ? sk : bk;
+        const float wsecond = wave_min(oval);
+        int cand2 = (oval == wsecond) ? okk : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand2 = min(cand2, __shfl_xor(cand2, o, 64));
+        if (lane == 0 && cand2 != 0x7fffffff) {
+            float d1, n1, d2, n2;
+            const float f1 = final_dist(cand, d1, n1), f2 = final_dist(cand2, d2, n2);
+            const float R = fmax_ - fmin_;
+            float m = INFINITY;
+            if (R > 0.f) {
+                const float s1 = (f1 > 0.f ? n1 / f1 : 1.f) * d1 / R, s2 = (f2 > 0.f ? n2 / f2 : 1.f) * d2 / R;
+                if (s1 + s2 > 0.f) m = 2.f * (f2 - f1) / (s1 + s2);
+            }
             if (!(m == m) || m < 0.f) m = 0.f;
             atomicMin(reinterpret_cast<unsigned*>(ctl + CTL_MARGIN), __float_as_uint(m));   // non-negative floats order like their bits
             if (m < NEAR_TIE) atomicAdd(ctl + CTL_NEAR, 1);

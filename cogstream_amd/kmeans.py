@@ -19,8 +19,9 @@ from . import ops
 
 last_stats = {"kpp_passes": 0, "iterations": 0, "kpp_path": "", "min_rel_margin": float("inf"), "rows_below_1e-3": 0}
 """of the most recent call (bench.py: bytes moved per stage; DESIGN.md section 2: how close the assignments were).
-min_rel_margin = smallest (second-best - best) / best final distance over all rows and Lloyd iterations; rows_below_1e-3
-= (row, iteration) pairs under 1e-3, where the reference's own cdist rounding decides a row."""
+min_rel_margin = over all rows and Lloyd iterations, the smallest relative change of a row's feature distances that
+would flip its cluster (cogs_kmeans_margins; (d2 - d1) / mean(d1, d2) of the two nearest centres when the time terms are
+equal); rows_below_1e-3 = (row, iteration) pairs under 1e-3, where the reference's own cdist rounding decides a row."""
 
 
 def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int, alpha: float = 2,

@@ -236,11 +236,13 @@ cogs_status cogs_kmeans_lloyd(cogs_stream stream, int dtype, const void* feats, 
                               float alpha, int max_iter, float tol, const int32_t* reseed_pool, int pool_len,
                               float* centres, float* centre_ts, int64_t* assign, int* iterations, int* reseeds_used,
                               int* pool_exhausted, void* ws, size_t ws_bytes);
-/* How close the assignments of the LAST cogs_kmeans_lloyd call on this workspace were (host outputs; synchronises):
- * *min_margin = the smallest (second-best - best) / best of the final distance sqrt(nf^2 + alpha nt^2) over all rows and
- * iterations, *rows_below = the number of (row, iteration) pairs with a margin below 1e-3. Below that margin the
- * reference's own torch.cdist rounding decides the row and no other summation order reproduces it;
- * at or above it the assignment equals the reference's. */
+/* How close the assignments of the LAST cogs_kmeans_lloyd call on this workspace were (host outputs; synchronises).
+ * Per row and iteration: the relative change of the row's feature distances that would flip the decision between its
+ * best and second-best cluster -- with every time term equal this is (d2 - d1) / mean(d1, d2) of the two nearest feature
+ * distances, the margin of the near-tie study; a decision the feature distances cannot flip is
+ * +inf. *min_margin = the minimum over all rows and iterations, *rows_below = the number of (row, iteration) pairs
+ * below 1e-3. Below that margin the reference's own torch.cdist rounding decides the row and no other summation order
+ * reproduces it; at or above it the assignment equals the reference's. */
 cogs_status cogs_kmeans_margins(cogs_stream stream, int T, int64_t PD, int K, void* ws, size_t ws_bytes, float* min_margin,
                                 int32_t* rows_below);
 /* dtype conversion / zero-padded row copy (features.to(float32), patch padding) */

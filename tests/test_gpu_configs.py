@@ -178,6 +178,34 @@ def test_cfg3_event_selection_reaches_kmeans_at_full_size(dev, model7b):
     assert all(int(mask[f].sum()) == 1 and bool(mask[f, 0]) for f in minor)         # one pooled token per minor frame
     assert ids.shape == (1, 4)
     model.cosine_override = None
+    # How close were the k-means decisions on REAL encoder outputs (not planted data)? The product reports the smallest
+    # relative margin between the best and the second-best cluster of any row in any iteration. At or above 1e-3 the
+    # reference's arithmetic (torch.cdist's sgemm form, oracle.kmeans with its default distances) must give the same
+    # assignment; below it the reference's own rounding decides and only the count is recorded.
+    from cogstream_amd import kmeans as km
+    from oracle import kmeans as ok
+    ts = torch.arange(256, dtype=torch.float32)
+    for kind in ("drift", "noise"):
+        clip_k = clip if kind == "drift" else np.concatenate([pr.synthetic_clip(64, kind="noise", clip_idx=c)[0] for c in range(4)])
+        ft = pr.CogStreamProcessor(tok, device=dev).process_images([("video", clip_k)])
+        mm = model.encode_images(ft["pixel_values"], ft["grid_sizes"], ft["merge_sizes"])
+        feats = mm.view(256, 50, 3584)
+        random.seed(11)
+        torch.manual_seed(11)
+        _, _, assign = km.kmeans_with_time_min_max(feats, ts, 18)
+        st = dict(km.last_stats)
+        print(f"k-means margins on cfg3 '{kind}' encoder outputs: min relative margin {st['min_rel_margin']:.3e}, "
+              f"(row, iteration) pairs below 1e-3: {st['rows_below_1e-3']} of {256 * st['iterations']} ({st['iterations']} iterations), "
+              f"k-means++ path: {st['kpp_path']}")
+        assert st["kpp_path"] == "one call" and st["min_rel_margin"] >= 0 and st["iterations"] >= 1
+        random.seed(11)
+        torch.manual_seed(11)
+        _, _, want = ok.kmeans_with_time_min_max(feats.float().cpu(), ts, 18)
+        same = bool(torch.equal(assign.cpu(), want))
+        print(f"    reference arithmetic (oracle, torch.cdist's sgemm form) gives the same 256 assignments: {same}"
+              + ("" if same else f" ({int((assign.cpu() != want).sum())} rows differ)"))
+        if st["rows_below_1e-3"] == 0:
+            assert same, kind
 
 
 def test_cfg4_eight_turn_session_caches_are_transparent_at_full_size(dev, model7b):

@@ -651,3 +651,73 @@ def test_image_modality_vs_reference(dev):
     ids, _ = model.generate(**inputs, max_new_tokens=4)
     assert ids.shape[0] == 1 and 1 <= ids.shape[1] <= 4
     assert bool(model.last_debug["compression_mask"].all())        # an image keeps all its tokens
+
+
+def test_kmeans_pp_in_one_call_equals_the_step_by_step_seeding(dev, monkeypatch):
+    """cogs_kmeans_pp (the K - 1 k-means++ draws on the device from host-made Exponential(1) rows: torch.multinomial(p, 1)
+    on the CPU is argmax(p / q)) against the step-by-step path that calls torch.multinomial itself: the same centres, the
+    same final assignment, and BOTH host generators (python random, torch CPU) left at the same position. All-identical
+    rows make every probability zero -- the reference's random.randint branch -- and must take the step-by-step path."""
+    from cogstream_amd import kmeans as km
+    from cogstream_amd import ops
+    T, P, D, K = 200, 4, 64, 14
+    g = torch.Generator().manual_seed(77)
+    cent = torch.randn(K, P * D, generator=g) * 2
+    feats = (cent[torch.randint(0, K, (T,), generator=g)] + 0.7 * torch.randn(T, P * D, generator=g)).view(T, P, D)
+    ts = torch.arange(T, dtype=torch.float32)
+    real_pp = ops.kmeans_pp
+
+    def forced_fallback(*a):                      # pretend a step found all probabilities zero
+        idx, flag = real_pp(*a)
+        flag.fill_(1)
+        return idx, flag
+
+    for dtype in (torch.float32, torch.bfloat16):
+        x = feats.to(dev, dtype)
+        for seed in (0, 1, 2, 3):
+            res = {}
+            for path in ("one call", "steps"):
+                monkeypatch.setattr(ops, "kmeans_pp", real_pp if path == "one call" else forced_fallback)
+                random.seed(seed)
+                torch.manual_seed(seed)
+                cf, ct, assign = km.kmeans_with_time_min_max(x, ts, K)
+                res[path] = (cf.clone(), ct.clone(), assign.clone(), random.random(), float(torch.rand(1)), km.last_stats["kpp_path"])
+            a, b = res["one call"], res["steps"]
+            assert a[5] == "one call" and b[5].startswith("step by step")
+            assert torch.equal(a[2], b[2]) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (dtype, seed)
+            assert a[3] == b[3] and a[4] == b[4], (dtype, seed)               # generator positions
+    monkeypatch.setattr(ops, "kmeans_pp", real_pp)
+    same = torch.ones(40, 2, 64).to(dev)
+    random.seed(5)
+    torch.manual_seed(5)
+    _, _, assign = km.kmeans_with_time_min_max(same, torch.zeros(40), 6)
+    assert km.last_stats["kpp_path"].startswith("step by step") and assign.shape == (40,)
+
+
+def test_kmeans_margin_statistics_flag_the_planted_near_ties(dev):
+    """last_stats["min_rel_margin"] / ["rows_below_1e-3"]: on the near-tie study's inputs (rows planted between two
+    centres at relative margins down to 1e-9) the statistic must see margins far below 1e-3 and count those rows; on
+    well-separated clusters it must stay above the threshold with a count of zero"""
+    from golden.tie_inputs import K, tie_inputs
+    from cogstream_amd import kmeans as km
+    from cogstream_amd import ops
+    inp = tie_inputs()
+    x = inp["features"].to(dev)
+    T = x.shape[0]
+    flat = x.view(T, -1)
+    ws = ops.kmeans_workspace(T, flat.shape[1], K, dev)
+    centres = flat[:K].clone().contiguous()
+    cts = torch.zeros(K, device=dev)
+    assign = torch.empty(T, dtype=torch.int64, device=dev)
+    it, _, _ = ops.kmeans_lloyd(flat, torch.zeros(T, device=dev), centres, cts, assign, 2.0, 1, 1e-4, [0] * 8, ws)
+    m, n = ops.kmeans_margins(T, flat.shape[1], K, ws)
+    margin = torch.from_numpy(_load("kmeans_ties.npz")["margin"])[K:]           # per planted row, fp64, of the feature distance
+    # fp32 resolves the planted margins down to ~1e-6; rows within 10 % of the threshold may fall on either side
+    assert it == 1 and 0 <= m < 1e-5 and int((margin < 9e-4).sum()) <= n <= int((margin < 1.1e-3).sum())
+    g = torch.Generator().manual_seed(1)
+    cent = torch.randn(6, 256, generator=g) * 10
+    sep = (cent[torch.arange(120) % 6] + 0.1 * torch.randn(120, 256, generator=g)).view(120, 1, 256).to(dev)
+    random.seed(0)
+    torch.manual_seed(0)
+    km.kmeans_with_time_min_max(sep, torch.zeros(120), 6)
+    assert km.last_stats["rows_below_1e-3"] == 0 and km.last_stats["min_rel_margin"] > 1e-3
