@@ -129,8 +129,10 @@ def stage_rooflines(c3, mm3, dev, with_cpu=True):
     out = [hbm_stage("kmeans_with_time_min_max (A8)", "sqdist_kernel / update_kernel (csrc/kmeans.hip)",
                      "model/kmeans_with_time.py:4-137", passes * T3 * P3 * D * es, t_km,
                      f"[{T3},{P3 * D}] bf16 features, K={K}: {st['kpp_passes']} k-means++ passes + {st['iterations']} Lloyd "
-                     f"iterations x 2 passes (distances, means) over the features; wall time of the whole call with the "
-                     f"reference's host RNG draws in the loop")]
+                     f"iterations x 2 passes (distances, means) over the features; wall time of the whole call (seeding in one "
+                     f"library call from host-drawn exponentials, Lloyd iterations queued four at a time; {st.get('kpp_path', '')})",
+                     )]
+    out[0]["min_rel_margin"], out[0]["rows_below_1e-3"] = st.get("min_rel_margin"), st.get("rows_below_1e-3")
     pix3 = c3["pix"]
     gh3, gw3 = c3["gh"], c3["gw"]
     Pm = gh3 * gw3 // 4
@@ -533,7 +535,7 @@ def main() -> None:
         # passes: FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction). The figure is read from the
         # PMC summary of the same command committed under profiles/ (tools/collect_profiles.sh), and labelled so.
         traffic, traffic_src = None, None
-        for name in ("r3_gemm_traffic.json", "r2_gemm_traffic.json", "r1_g_gemm_traffic.json"):
+        for name in ("r4_gemm_traffic.json", "r3_gemm_traffic.json", "r2_gemm_traffic.json", "r1_g_gemm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if world == 1 and T == 64 and not cfg3 and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")

@@ -119,6 +119,7 @@ SIGNATURES = {
     "cogs_version": (C.c_char_p, []),
     "cogs_create": (c_int, [c_int, C.POINTER(c_void_p)]),
     "cogs_destroy": (c_int, [c_void_p]),
+    "cogs_vit_set_streams": (c_int, [c_void_p, c_int]),
     "cogs_profile_begin": (c_int, [c_void_p]),
     "cogs_profile_end": (c_int, [c_void_p, c_void_p, C.POINTER(c_float), C.POINTER(c_int)]),
     "cogs_gemm": (c_int, [c_void_p, C.POINTER(GemmDesc)]),

@@ -42,6 +42,7 @@ struct cogs_ctx {
     // second stream of the frame-split encode (cogs_vit_encode): two halves of a small clip run side by side
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int vit_streams = 2;                  // cogs_vit_set_streams: 1 = never split
     // optional per-kernel-class event profiling (bench/roofline only)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;      // pairs
@@ -409,6 +410,12 @@ static size_t vit_carve(const cogs_vit_weights& w, int64_t N, int nframes, Carve
     return c.off;
 }
 
+cogs_status cogs_vit_set_streams(cogs_handle h, int streams) {
+    if (!h || streams < 1 || streams > 2) return COGS_E_INVALID;
+    h->vit_streams = streams;
+    return COGS_OK;
+}
+
 cogs_status cogs_vit_workspace_bytes(cogs_handle h, int64_t n_patches, size_t* bytes) {
     if (!h || !h->vit_ok || !bytes || n_patches <= 0) return COGS_E_INVALID;
     Carver c(nullptr, 0);
@@ -447,7 +454,7 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
     }
     static const bool env_single = getenv("COGS_VIT_STREAMS") && atoi(getenv("COGS_VIT_STREAMS")) == 1;
     static const int64_t split_max = getenv("COGS_VIT_SPLIT_MAX") ? atoll(getenv("COGS_VIT_SPLIT_MAX")) : VIT_SPLIT_MAX_PATCHES;
-    if (!env_single && !h->prof_on && attn_mode == COGS_ATTN_BLOCK_DIAG && nframes >= 2 && N <= split_max) {
+    if (!env_single && h->vit_streams > 1 && !h->prof_on && attn_mode == COGS_ATTN_BLOCK_DIAG && nframes >= 2 && N <= split_max) {
         // cut at the frame boundary nearest to half the patches
         std::vector<int64_t> ga, gb, ma, mb;
         int64_t rows_a = 0, toks_a = 0, fa = 0, best_gap = N + 1, acc = 0;
@@ -474,10 +481,17 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
         const size_t need_b = vit_carve(w, N - rows_a, (int)(nframes - fa), cb, &p0, &p1, &p2, &p3, &q0, &q1, &i0, &i1, &i2);
         bool ok = ws && need_a + need_b <= ws_bytes && !ma.empty() && !mb.empty();
         if (ok && !h->aux_stream) {
-            ok = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
-            if (!ok) h->aux_stream = nullptr;
+            hipStream_t s2 = nullptr;
+            hipEvent_t e1 = nullptr, e2 = nullptr;
+            ok = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
+            if (ok) { h->aux_stream = s2; h->ev_fork = e1; h->ev_join = e2; }
+            else {      // whatever was created goes back; the clip is encoded on the caller's stream alone
+                if (e2) (void)hipEventDestroy(e2);
+                if (e1) (void)hipEventDestroy(e1);
+                if (s2) (void)hipStreamDestroy(s2);
+            }
         }
         if (ok) {
             const size_t pes = pix_dtype == COGS_DT_BF16 ? 2 : 4;

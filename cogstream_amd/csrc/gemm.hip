@@ -769,7 +769,9 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         const int nb = p.nbm * p.nbn;
         const int rounds = nb / PERSISTENT_WGS, rem = nb % PERSISTENT_WGS;
         int mb_main = -1;      // >= 0: row blocks that stay in this kernel (0 = none: the whole GEMM goes to the ring kernel)
-        if (!env_nosplit && !env_nostore && nb <= 2 * PERSISTENT_WGS) {
+        // (calibrated on K = 1152 .. 4352, the ViT shapes; longer K -- the Qwen2 prompt pass at M = 2048 -- keeps the
+        // plain ping-pong launch)
+        if (!env_nosplit && !env_nostore && nb <= 2 * PERSISTENT_WGS && g.K <= 4352) {
             // Few tiles (one rank's share of a frame-sharded clip: M = 6 400 is 125 tiles for N = 1152 and 350 = 1.37
             // rounds for QKV): the time is rounds x one tile, so the choice is by rounds. Calibrated on the four ViT
             // shapes at M = 3 200 .. 14 784 (tools/cal_tiles.sh, rocprofv3): a round of 256x128 ring tiles takes 0.64-0.68 of a
@@ -784,7 +786,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
             if (rounds == 1 && rem > 0) {
                 const int mb = PERSISTENT_WGS / p.nbn;                 // whole row blocks inside the first round
                 const int rows_rem = g.M - mb * BM3;
-                if (mb > 0 && rows_rem >= 256) {
+                if (mb > 0 && rows_rem >= 512) {     // the remainder must reach the 256x128 ring kernel the cost model prices
                     const float cost_split = 1.f + c_ring * ring_rounds((rows_rem + BM2 - 1) / BM2) + c_launch;
                     if (cost_split < best) { best = cost_split; mb_main = mb; }
                 }

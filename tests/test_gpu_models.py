@@ -91,6 +91,14 @@ def test_frame_split_two_stream_encode_is_transparent(dev):
                                out.data_ptr(), ws.data_ptr(), ws.numel())
     torch.cuda.synchronize()
     assert rc == L.OK and torch.equal(out, whole)
+    # split against UNSPLIT, explicitly: cogs_vit_set_streams(1) keeps the clip on the caller's stream
+    try:
+        L.check(L.lib.cogs_vit_set_streams(enc.handle.h, 1))
+        single = enc(pix, grids, merges)
+    finally:
+        L.check(L.lib.cogs_vit_set_streams(enc.handle.h, 2))
+    assert torch.equal(single, whole)
+    assert L.lib.cogs_vit_set_streams(enc.handle.h, 3) == L.E_INVALID
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
