@@ -295,6 +295,30 @@ def process_history_qas(conversation: List[Dict[str, Any]]) -> Tuple[List[str], 
     return qs[:-1], ans, (qs[-1] if qs else "")
 
 
+def content_key(v) -> str:
+    """content key of one clip / image for the model's visual-token cache (CogReasoner.enable_visual_cache). Host arrays:
+    xxh64 of the raw bytes, hashed in place. Tensors already on the GPU are fingerprinted THERE (two position-weighted
+    64-bit sums over the bytes, ~0.1 ms for a 256-frame 480p clip) -- copying 315 MB back to the host just to hash them
+    cost 58 ms per request, more than encoding the clip."""
+    import torch
+    if isinstance(v, torch.Tensor) and v.is_cuda:
+        b = v.contiguous().view(torch.uint8).reshape(-1)
+        n = b.numel()
+        pad = (-n) % 8
+        if pad:
+            b = torch.cat([b, b.new_zeros(pad)])
+        w = b.view(torch.int64)
+        i = torch.arange(w.numel(), device=w.device, dtype=torch.int64)
+        # odd multipliers that depend on the position (wrapping int64 arithmetic): a swap or a change of any word moves both sums
+        s1 = (w * (2 * i + 0x9E3779B97F4A7C15 % (1 << 62) | 1)).sum()
+        s2 = ((w ^ (w >> 29)) * ((i * 0x2545F4914F6CDD1D % (1 << 62)) | 1)).sum()
+        a, c = (int(x) & 0xFFFFFFFFFFFFFFFF for x in torch.stack([s1, s2]).tolist())
+        return f"gpu:{a:016x}{c:016x}:{tuple(v.shape)}"
+    import xxhash
+    arr = np.ascontiguousarray(v.cpu().numpy() if isinstance(v, torch.Tensor) else v)
+    return xxhash.xxh64(memoryview(arr).cast("B")).hexdigest()
+
+
 def _as_frames(x) -> Any:
     """an image / clip as handed over by a caller -> uint8 [t, H, W, 3] (numpy, or a torch tensor left where it is)"""
     import torch
@@ -483,10 +507,7 @@ class CogStreamProcessor:
         text = render_conversation(conv, add_system_prompt, add_generation_prompt)
         enc, text = self.process_text(text, feats)
         hist_qs, hist_as, cur_q = process_history_qas(conversation)
-        # content keys of the media (xxh64 of the raw bytes) for the model's visual-token cache
-        import xxhash
-        video_keys = [xxhash.xxh64(memoryview(np.ascontiguousarray(v.cpu().numpy() if isinstance(v, torch.Tensor) else v))
-                                   .cast("B")).hexdigest() for v in frames]   # hashed in place: no copy of the frames
+        video_keys = [content_key(v) for v in frames]      # for the model's visual-token cache
         total_image_num = sum(int(v.shape[0]) for v in frames)     # :656-658
         out = {
             "video_keys": video_keys,

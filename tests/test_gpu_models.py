@@ -647,3 +647,21 @@ def test_ragged_frame_shards_equal_whole_clip_bit_for_bit(dev):
         a = enc(pix[:cut * 200], torch.tensor([[cut, gh, gw]]), merge).clone()
         b = enc(pix[cut * 200:], torch.tensor([[T - cut, gh, gw]]), merge).clone()
         assert torch.equal(whole, torch.cat([a, b])), cut
+
+
+def test_content_key_of_gpu_resident_clips(dev):
+    """processing.content_key fingerprints a clip that already lives on the GPU there (no 300 MB copy back to the host
+    per request): equal content -> equal key, any changed byte / swapped frames / other shape -> another key"""
+    from cogstream_amd import processing as pr
+    clip = torch.from_numpy(pr.synthetic_clip(6, 60, 100, kind="drift", clip_idx=3)[0]).to(dev)
+    k0 = pr.content_key(clip)
+    assert k0.startswith("gpu:") and k0 == pr.content_key(clip.clone())
+    other = clip.clone()
+    other[3, 17, 5, 1] ^= 1
+    swapped = clip[[1, 0, 2, 3, 4, 5]].contiguous()
+    keys = {k0, pr.content_key(other), pr.content_key(swapped), pr.content_key(clip[:5].contiguous()),
+            pr.content_key(clip.view(6, 100, 60, 3))}
+    assert len(keys) == 5
+    proc = pr.CogStreamProcessor(__import__("toy_tokenizer").ToyTokenizer(), device=dev)
+    conv = [{"role": "user", "content": [{"type": "video", "video": clip, "timestamps": [0.0, 1, 2, 3, 4, 5]}, {"type": "text", "text": "q?"}]}]
+    assert proc(conversation=conv)["video_keys"] == [k0]
