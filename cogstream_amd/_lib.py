@@ -142,8 +142,8 @@ SIGNATURES = {
     "cogs_select_near_centroid": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cogs_kmeans_pp_step": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_size_t]),
-    "cogs_kmeans_pp": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_size_t]),
+    "cogs_kmeans_pp": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_size_t]),
     "cogs_kmeans_margins": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "cogs_kmeans_lloyd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_int, c_float,
                                   c_void_p, c_int, c_void_p, c_void_p, c_void_p, C.POINTER(c_int), C.POINTER(c_int),

@@ -298,13 +298,13 @@ cogs_status cogs_kmeans_pp_step(cogs_stream stream, int dtype, const void* feats
     if (!feats || !nearest2 || T <= 0) return COGS_E_INVALID;
     return cogs_k_kmeans_pp_step((hipStream_t)stream, dtype, feats, T, PD, row, first, nearest2, probs_host, (float*)ws, ns);
 }
-cogs_status cogs_kmeans_pp(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD, int K, const float* q_draws,
-                           int32_t* idx, int32_t* zero_flag, float* nearest2, void* ws, size_t ws_bytes) {
+cogs_status cogs_kmeans_pp(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD, int K, int first_row,
+                           const float* q_draws, int32_t* idx, int32_t* zero_flag, float* nearest2, void* ws, size_t ws_bytes) {
     int ns = 0;
     const size_t need = cogs_k_kmeans_ws(T, PD, 1, &ns);
     if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
     if (!feats || !q_draws || !idx || !zero_flag || !nearest2 || T <= 0 || K <= 0) return COGS_E_INVALID;
-    return cogs_k_kmeans_pp((hipStream_t)stream, dtype, feats, T, PD, K, q_draws, idx, zero_flag, nearest2, (float*)ws, ns);
+    return cogs_k_kmeans_pp((hipStream_t)stream, dtype, feats, T, PD, K, first_row, q_draws, idx, zero_flag, nearest2, (float*)ws, ns);
 }
 cogs_status cogs_kmeans_margins(cogs_stream stream, int T, int64_t PD, int K, void* ws, size_t ws_bytes, float* min_margin,
                                 int32_t* rows_below) {

@@ -120,7 +120,7 @@ int cogs_k_kmeans_sqdist(hipStream_t st, int dtype, const void* feats, int T, lo
                          const int* centre_rows, int K, float* ws, int nslices, float* dist2);
 int cogs_k_kmeans_pp_step(hipStream_t st, int dtype, const void* feats, int T, long PD, int row, int first,
                           float* nearest2, float* probs_host, float* ws, int nslices);
-int cogs_k_kmeans_pp(hipStream_t st, int dtype, const void* feats, int T, long PD, int K, const float* q, int* idx,
+int cogs_k_kmeans_pp(hipStream_t st, int dtype, const void* feats, int T, long PD, int K, int first_row, const float* q, int* idx,
                      int* zero_flag, float* nearest2, float* ws, int nslices);
 int cogs_k_kmeans_margins(hipStream_t st, int T, long PD, int K, float* ws, float* min_margin, int* rows_below);
 int cogs_k_kmeans_lloyd(hipStream_t st, int dtype, const void* feats, const float* ts, int T, long PD, int K, float alpha,

@@ -37,7 +37,7 @@ enum { CTL_USED = 0,      // reseed-pool entries consumed so far
        CTL_SHIFT = 3,     // centre shift of the last committed iteration (float bits)
        CTL_DONE = 4,      // shift <= tol: converged
        CTL_ITERS = 5,     // iterations committed
-       CTL_MARGIN = 6,    // min over rows and iterations of the decision margin (reduce_assign_kernel; float bits, >= 0)
+       CTL_MARGIN = 6,    // bits(+inf) - bits(min over rows and iterations of the decision margin) (reduce_assign_kernel)
        CTL_NEAR = 7,      // rows (summed over iterations) whose margin is below NEAR_TIE
        CTL_WORDS = 8 };
 constexpr float NEAR_TIE = 1e-3f;   // below this the reference's own sgemm rounding decides a row
@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256) void reduce_assign_kernel(const float* __restr
                 if (s1 + s2 > 0.f) m = 2.f * (f2 - f1) / (s1 + s2);
             }
             if (!(m == m) || m < 0.f) m = 0.f;
-            atomicMin(reinterpret_cast<unsigned*>(ctl + CTL_MARGIN), __float_as_uint(m));   // non-negative floats order like their bits
+            // non-negative floats order like their bits; kept as the MAXIMUM of (bits(+inf) - bits(m)) so that the
+            // all-zero control block the loop starts from means "margin = +inf"
+            atomicMax(reinterpret_cast<unsigned*>(ctl + CTL_MARGIN), 0x7f800000u - __float_as_uint(m));
             if (m < NEAR_TIE) atomicAdd(ctl + CTL_NEAR, 1);
         }
     }
@@ -289,11 +291,12 @@ __global__ __launch_bounds__(256) void reduce_assign_kernel(const float* __restr
 // path. One workgroup; the sum runs in fp64 in a fixed order (torch's own fp32 summation order is not reproduced: the sum
 // is a common divisor of all ratios and only moves the argmax between ratios closer than a few ulps).
 __global__ __launch_bounds__(256) void kpp_select_kernel(const float* __restrict__ nearest2, const float* __restrict__ q, int Tn,
-                                                         int* __restrict__ idx_out, int* __restrict__ zero_flag) {
+                                                         int* __restrict__ idx_out, int* __restrict__ zero_flag, int first_row) {
     __shared__ double red[4];
     __shared__ float rv[4];
     __shared__ int ri[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (first_row >= 0 && tid == 0) idx_out[-1] = first_row;      // step 1 also records the caller's first centre
     double sum = 0.0;
     for (int t = tid; t < Tn; t += 256) {
         const float d = sqrtf(nearest2[t]);
@@ -792,17 +795,22 @@ int cogs_k_kmeans_pp_step(hipStream_t st, int dtype, const void* feats, int T, l
 // torch.multinomial calls would make on the CPU generator, made ahead by the host. idx: device int32 [K], idx[0] given.
 // *zero_flag (device int, zeroed here) is set when a step found all probabilities zero -- the reference's
 // random.randint branch; the indices from that step on are then meaningless and the caller redoes the seeding step by step.
-int cogs_k_kmeans_pp(hipStream_t st, int dtype, const void* feats, int T, long PD, int K, const float* q, int* idx,
+int cogs_k_kmeans_pp(hipStream_t st, int dtype, const void* feats, int T, long PD, int K, int first_row, const float* q, int* idx,
                      int* zero_flag, float* nearest2, float* ws, int nslices) {
-    if (T <= 0 || K <= 0 || PD % 8 || !q || !idx || !zero_flag || !nearest2) return COGS_E_INVALID;
+    if (T <= 0 || K <= 0 || PD % 8 || !q || !idx || !zero_flag || !nearest2 || first_row < 0 || first_row >= T) return COGS_E_INVALID;
     const KmWs w = carve(ws, T, PD, 1);
     if (hipMemsetAsync(zero_flag, 0, sizeof(int), st) != hipSuccess) return COGS_E_HIP;
     for (int m = 1; m < K; ++m) {
-        const int rc = sqdist_partials(st, dtype, feats, T, PD, nullptr, idx + (m - 1), -1, 1, w.partial, nslices);
+        // step 1 measures against the caller's first centre (a kernel argument: nothing is uploaded), later steps against
+        // the row the previous step drew (read from device memory)
+        const int rc = m == 1 ? sqdist_partials(st, dtype, feats, T, PD, nullptr, nullptr, first_row, 1, w.partial, nslices)
+                              : sqdist_partials(st, dtype, feats, T, PD, nullptr, idx + (m - 1), -1, 1, w.partial, nslices);
         if (rc != COGS_OK) return rc;
         hipLaunchKernelGGL(reduce_min_kernel, dim3((T + 3) / 4), dim3(256), 0, st, w.partial, nslices, T, m == 1 ? 1 : 0, nearest2);
-        hipLaunchKernelGGL(kpp_select_kernel, dim3(1), dim3(256), 0, st, nearest2, q + (size_t)(m - 1) * T, T, idx + m, zero_flag);
+        hipLaunchKernelGGL(kpp_select_kernel, dim3(1), dim3(256), 0, st, nearest2, q + (size_t)(m - 1) * T, T, idx + m, zero_flag,
+                           m == 1 ? first_row : -1);
     }
+    if (K == 1 && hipMemcpyAsync(idx, &first_row, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) return COGS_E_HIP;
     return COGS_LAUNCH_CHECK();
 }
 
@@ -814,7 +822,11 @@ int cogs_k_kmeans_pp(hipStream_t st, int dtype, const void* feats, int T, long P
 // draws more and calls again with the remaining budget).
 constexpr int LLOYD_BATCH = 4;
 namespace {
+// host-mapped: [0, 64) the control words as update_final leaves them, [64, 64 + 4 * POOL_MAX) the reseed pool -- the
+// device reads the pool in place (only when a cluster runs empty), so a call uploads nothing and frees the caller's
+// array the moment it returns
 struct StatusBlock { volatile int* h = nullptr; int* d = nullptr; int dev = -1; };
+constexpr size_t STATUS_BYTES = 64 + (size_t)POOL_MAX * 4;
 // one host-mapped block per calling thread; replaced (and the old one freed) when the thread's device changes
 bool status_block(StatusBlock& b) {
     int dev = 0;
@@ -822,7 +834,7 @@ bool status_block(StatusBlock& b) {
     if (b.h && b.dev == dev) return true;
     if (b.h) { (void)hipHostFree((void*)b.h); b.h = nullptr; b.d = nullptr; }
     void* hp = nullptr;
-    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) return false;
+    if (hipHostMalloc(&hp, STATUS_BYTES, hipHostMallocMapped) != hipSuccess) return false;
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipHostFree(hp); return false; }
     b.h = (volatile int*)hp; b.d = (int*)dp; b.dev = dev;
@@ -842,13 +854,10 @@ int cogs_k_kmeans_lloyd(hipStream_t st, int dtype, const void* feats, const floa
     if (exhausted) *exhausted = 0;
     if (max_iter == 0) return COGS_OK;             // nothing to do
     const KmWs w = carve(ws, T, PD, K);
-    {   // control words: zero, margin = +inf
-        int init[CTL_WORDS] = {0, 0, 0, 0, 0, 0, 0x7f800000, 0};
-        // (both copies are synchronous with respect to the host buffers: at most 16 KiB, and the caller may free pool_host
-        // right after an error return)
-        if (hipMemcpy(w.ctl, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) return COGS_E_HIP;
-        if (pool_len > 0 && hipMemcpy(w.pool, pool_host, (size_t)pool_len * 4, hipMemcpyHostToDevice) != hipSuccess) return COGS_E_HIP;
-    }
+    if (hipMemsetAsync(w.ctl, 0, CTL_WORDS * sizeof(int), st) != hipSuccess) return COGS_E_HIP;     // margin word 0 = +inf
+    int* pool_d = sb.d + 16;
+    for (int i = 0; i < pool_len; ++i) sb.h[16 + i] = pool_host[i];        // plain host stores into the mapped block
+    for (int i = 0; i < CTL_WORDS; ++i) sb.h[i] = 0;
     int queued = 0, it = 0, used = 0, ex = 0;
     int rc = COGS_OK;
     while (queued < max_iter) {
@@ -856,7 +865,7 @@ int cogs_k_kmeans_lloyd(hipStream_t st, int dtype, const void* feats, const floa
         for (int b = 0; b < batch && rc == COGS_OK; ++b) {
             rc = sqdist_partials(st, dtype, feats, T, PD, centres, nullptr, -1, K, w.partial, nslices, w.ctl);
             if (rc == COGS_OK) rc = launch_reduce_assign(st, w.partial, nslices, T, K, ts, centre_ts, alpha, nullptr, assign, w.ctl);
-            if (rc == COGS_OK) rc = launch_members(st, assign, T, K, w, w.pool, pool_len, nullptr, w.ctl);
+            if (rc == COGS_OK) rc = launch_members(st, assign, T, K, w, pool_d, pool_len, nullptr, w.ctl);
             if (rc == COGS_OK) rc = launch_update(st, dtype, feats, ts, T, PD, K, w, w.ctl, centres, centre_ts, (float*)(w.ctl + CTL_SHIFT),
                                                   (volatile int*)sb.d, tol);
         }
@@ -882,7 +891,7 @@ int cogs_k_kmeans_margins(hipStream_t st, int T, long PD, int K, float* ws, floa
     int h[CTL_WORDS];
     if (hipMemcpyAsync(h, w.ctl, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return COGS_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return COGS_E_HIP;
-    if (min_margin) *min_margin = __builtin_bit_cast(float, h[CTL_MARGIN]);
+    if (min_margin) *min_margin = __builtin_bit_cast(float, 0x7f800000 - h[CTL_MARGIN]);
     if (rows_below) *rows_below = h[CTL_NEAR];
     return COGS_OK;
 }

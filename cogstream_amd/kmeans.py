@@ -24,6 +24,37 @@ would flip its cluster (cogs_kmeans_margins; (d2 - d1) / mean(d1, d2) of the two
 equal); rows_below_1e-3 = (row, iteration) pairs under 1e-3, where the reference's own cdist rounding decides a row."""
 
 
+def _lloyd_from_rows(x, ts, rows, K: int, PD: int, alpha: float, max_iteration: int, tol: float, ws):
+    """Lloyd iterations (:71-131) from the centres x[rows], inside the library. Empty clusters are reseeded with
+    random.randint(0, T-1) per cluster in ascending order (:116-120): the values are drawn AHEAD into a pool the device
+    consumes in that order, and the generator is then put back to where the reference would have left it (state
+    restored, the used number of draws replayed). -> (centres [K, PD] fp32, centre_ts, assign, iterations)"""
+    T = x.shape[0]
+    centres = ops.pack_rows(x.index_select(0, rows), torch.float32, PD) if x.dtype != torch.float32 \
+        else x.index_select(0, rows).contiguous()
+    centre_ts = ts.index_select(0, rows).contiguous()
+    assign = torch.empty(T, dtype=torch.int64, device=x.device)
+    state = random.getstate()
+    left, done, used_total, pool_n = max_iteration, 0, 0, 2 * K
+    drawn: List[int] = []
+    while left > 0:
+        drawn.extend(random.randint(0, T - 1) for _ in range(pool_n))
+        it, used, exhausted = ops.kmeans_lloyd(x, ts, centres, centre_ts, assign, float(alpha), left, float(tol),
+                                               drawn[used_total:], ws)
+        done, left, used_total = done + it, left - it, used_total + used
+        if not exhausted:
+            break
+        pool_n = min(4096, max(pool_n * 2, K))     # an iteration wanted more reseeds than were left: draw more, go on
+        drawn = drawn[:used_total]
+        random.setstate(state)
+        for _ in range(used_total):
+            random.randint(0, T - 1)
+    random.setstate(state)
+    for _ in range(used_total):
+        random.randint(0, T - 1)
+    return centres, centre_ts, assign, done
+
+
 def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int, alpha: float = 2,
                              max_iteration: int = 30, tol: float = 1e-4
                              ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
@@ -48,14 +79,15 @@ def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int
     py_state, torch_state = random.getstate(), torch.get_rng_state()
     q = torch.stack([torch.empty(T, dtype=torch.float32).exponential_(1) for _ in range(K - 1)])
     idx_d, flag = ops.kmeans_pp(x, first, K, q.to(dev, non_blocking=True), ws)
-    got = torch.cat([idx_d, flag]).cpu().tolist()
-    if got[-1] == 0:
-        idx: List[int] = got[:K]
+    # (no host read here: the Lloyd loop below starts from the device-resident rows; the flag is looked at after its
+    # first synchronisation, and in the rare flagged case everything is redone step by step)
+    run = _lloyd_from_rows(x, ts, idx_d.to(torch.int64), K, PD, alpha, max_iteration, tol, ws)
+    if int(flag.item()) == 0:
         last_stats["kpp_path"] = "one call"
     else:
         random.setstate(py_state)
         torch.set_rng_state(torch_state)
-        idx = [first]
+        idx: List[int] = [first]
         nearest2 = torch.empty(T, dtype=torch.float32, device=dev)
         probs = torch.empty(T, dtype=torch.float32).pin_memory()
         while len(idx) < K:
@@ -68,34 +100,8 @@ def kmeans_with_time_min_max(features: torch.Tensor, timestamp, cluster_num: int
                 new = int(torch.multinomial(probs / s, 1).item())        # CPU generator, like the reference
             idx.append(new)
         last_stats["kpp_path"] = "step by step (a zero-probability step)"
-
-    rows = torch.tensor(idx, dtype=torch.int64, device=dev)
-    centres = ops.pack_rows(x.index_select(0, rows), torch.float32, PD) if x.dtype != torch.float32 \
-        else x.index_select(0, rows).contiguous()
-    centre_ts = ts.index_select(0, rows).contiguous()
-    assign = torch.empty(T, dtype=torch.int64, device=dev)
-    # ---- Lloyd iterations (:71-131) run inside the library (one host read per iteration). Empty clusters are reseeded
-    # with random.randint(0, T-1) per cluster in ascending order (:116-120): the values are drawn AHEAD into a pool the
-    # device consumes in that order, and the generator is then put back to where the reference would have left it
-    # (state restored, the used number of draws replayed) ----
-    state = random.getstate()
-    left, done, used_total, pool_n = max_iteration, 0, 0, 2 * K
-    drawn: List[int] = []
-    while left > 0:
-        drawn.extend(random.randint(0, T - 1) for _ in range(pool_n))
-        it, used, exhausted = ops.kmeans_lloyd(x, ts, centres, centre_ts, assign, float(alpha), left, float(tol),
-                                               drawn[used_total:], ws)
-        done, left, used_total = done + it, left - it, used_total + used
-        if not exhausted:
-            break
-        pool_n = min(4096, max(pool_n * 2, K))     # an iteration wanted more reseeds than were left: draw more, go on
-        drawn = drawn[:used_total]
-        random.setstate(state)
-        for _ in range(used_total):
-            random.randint(0, T - 1)
-    random.setstate(state)
-    for _ in range(used_total):
-        random.randint(0, T - 1)
+        run = _lloyd_from_rows(x, ts, torch.tensor(idx, dtype=torch.int64, device=dev), K, PD, alpha, max_iteration, tol, ws)
+    centres, centre_ts, assign, done = run
     last_stats["kpp_passes"], last_stats["iterations"] = K - 1, done
     last_stats["min_rel_margin"], last_stats["rows_below_1e-3"] = ops.kmeans_margins(T, PD, K, ws)
     return centres.view(K, P, D), centre_ts, assign

@@ -241,12 +241,11 @@ def kmeans_pp(feats, first_row: int, K: int, q_draws: torch.Tensor, ws):
     fp32 [K-1, T] Exponential(1) draws of the CPU generator"""
     T, PD = feats.shape
     assert q_draws.is_cuda and q_draws.dtype == torch.float32 and q_draws.shape == (K - 1, T) and q_draws.is_contiguous()
-    idx = torch.empty(K, device=feats.device, dtype=torch.int32)
-    idx[0] = int(first_row)
-    flag = torch.empty(1, device=feats.device, dtype=torch.int32)
+    buf = torch.empty(K + 1, device=feats.device, dtype=torch.int32)       # [K] centre rows + the flag, one allocation
+    idx, flag = buf[:K], buf[K:]
     nearest2 = torch.empty(T, device=feats.device, dtype=torch.float32)
-    check(L.lib.cogs_kmeans_pp(current_stream(), dtype_code(feats.dtype), ptr(feats), T, PD, int(K), ptr(q_draws), ptr(idx),
-                               ptr(flag), ptr(nearest2), ptr(ws), ws.numel()), "cogs_kmeans_pp")
+    check(L.lib.cogs_kmeans_pp(current_stream(), dtype_code(feats.dtype), ptr(feats), T, PD, int(K), int(first_row), ptr(q_draws),
+                               ptr(idx), ptr(flag), ptr(nearest2), ptr(ws), ws.numel()), "cogs_kmeans_pp")
     return idx, flag
 
 

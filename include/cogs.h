@@ -211,8 +211,8 @@ cogs_status cogs_select_near_centroid(cogs_stream stream, const float* dist2, co
  * Workspace: cogs_kmeans_workspace_bytes(T, PD, 1). */
 cogs_status cogs_kmeans_pp_step(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD, int row, int first,
                                 float* nearest2, float* probs_host, void* ws, size_t ws_bytes);
-/* The whole k-means++ seeding (:41-62) in ONE call, no host round trip per centre. idx (device int32 [K]): idx[0] = the
- * first centre (the caller's random.randint draw); entry m is written as the row drawn after m centres:
+/* The whole k-means++ seeding (:41-62) in ONE call, no host round trip per centre. first_row = the first centre (the
+ * caller's random.randint draw); idx (device int32 [K], all written): idx[0] = first_row, entry m the row drawn after m centres:
  * probs = (sqrt(nearest distance^2))^2 normalised by their sum, torch.multinomial(probs, 1) = argmax(probs / q), q ~
  * Exponential(1) (ATen's n_sample == 1 path) -- q_draws (device fp32 [K-1][T]) are those draws, made ahead on the
  * caller's CPU generator, one [T] row per centre, exactly as K - 1 multinomial calls would consume it. *zero_flag (device
@@ -220,15 +220,15 @@ cogs_status cogs_kmeans_pp_step(cogs_stream stream, int dtype, const void* feats
  * are then not usable and the caller seeds step by step with cogs_kmeans_pp_step instead. nearest2: device fp32 [T]
  * scratch. The sum of the probabilities is taken in fp64 in a fixed order, not in torch's fp32 summation order: it is a
  * common divisor of all ratios. Workspace: cogs_kmeans_workspace_bytes(T, PD, 1). */
-cogs_status cogs_kmeans_pp(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD, int K, const float* q_draws,
-                           int32_t* idx, int32_t* zero_flag, float* nearest2, void* ws, size_t ws_bytes);
+cogs_status cogs_kmeans_pp(cogs_stream stream, int dtype, const void* feats, int T, int64_t PD, int K, int first_row,
+                           const float* q_draws, int32_t* idx, int32_t* zero_flag, float* nearest2, void* ws, size_t ws_bytes);
 /* The whole Lloyd loop (:71-131) from given centres: per iteration distances -> assignment -> means / reseeds -> centre
  * shift, stopping after max_iter iterations or when the shift is <= tol. The library queues up to four iterations
  * between two synchronisations of the stream (it reads eight control words from host-mapped memory); every kernel of an
  * iteration queued behind the converged one returns without touching anything, so centres / assign are those of the
  * iteration the reference stops at. Empty clusters (:116-120: one random.randint(0, T-1) per empty cluster, ascending
  * cluster index, every iteration) take their rows from reseed_pool (HOST int32 [pool_len], pool_len <= 4096: the caller's
- * pre-drawn values, consumed in order, copied before the call returns; *reseeds_used reports how many). If an iteration
+ * pre-drawn values, consumed in order, copied into host-mapped memory before the first launch; *reseeds_used reports how many). If an iteration
  * needs more than are left it is NOT committed: the call returns COGS_OK with *pool_exhausted = 1 and *iterations = the
  * completed ones; draw more and call again with the remaining iteration budget. T + K + 1 <= 16 384 (the assignments
  * and the cluster counters are staged in LDS). Workspace: cogs_kmeans_workspace_bytes(T, PD, K). */

@@ -100,6 +100,10 @@ def test_kmeans_reseed_pool_runs_dry_and_resumes(dev, monkeypatch):
     calls = []
     real = ops.kmeans_lloyd
     monkeypatch.setattr(ops, "kmeans_lloyd", lambda *a: calls.append(real(*a)) or calls[-1])
+    # duplicate rows make a k-means++ step with all probabilities zero: the one-call seeding flags it and the product
+    # seeds again step by step (after a Lloyd run from the flagged rows that is thrown away) -- count the final run only
+    real_step = ops.kmeans_pp_step
+    monkeypatch.setattr(ops, "kmeans_pp_step", lambda *a: (calls.clear(), real_step(*a))[1])
     random.seed(seed)
     torch.manual_seed(seed)
     cf, ct, assign = km.kmeans_with_time_min_max(feats.to(dev), ts, K)
@@ -110,6 +114,7 @@ def test_kmeans_reseed_pool_runs_dry_and_resumes(dev, monkeypatch):
     for lab in a.unique().tolist():                                                    # each cluster's centre is its rows' value
         rows = feats[a == lab].reshape(-1, cf[0].numel())
         assert rel_err(cf[lab].reshape(-1).cpu(), rows[0]) < 1e-5
+    assert km.last_stats["kpp_path"].startswith("step by step")
     assert km.last_stats["iterations"] == 30 == sum(c[0] for c in calls)
     assert sum(1 for c in calls if c[2]) >= 3 and sum(c[1] for c in calls) == 210       # 30 iterations x 7 empty clusters
 
