@@ -151,3 +151,20 @@ def test_bench_gpus_2_starts_its_own_ranks(dev):
     assert d["config"]["frames"] == 64 and d["config"]["frames_per_gpu"] == 32
     assert d["cfg3"]["n_gpus"] == 2 and d["cfg3"]["frames_per_gpu"] == 128 and d["cfg3"]["scaling"] == "strong"
     assert d["weak"]["frames"] == 128 and d["weak"]["frames_per_gpu"] == 64
+
+
+def test_bench_cfg5_replicas_mode_on_two_ranks(dev):
+    """BASELINE configs[4] as a bench mode: `python bench.py --config cfg5 --gpus 2` -- every rank builds the whole model
+    and answers its OWN 64-frame 480p clip through processor -> qa_selection -> generate (replicas only, no collective);
+    value = frames of the answered clips per second of wall time. Rehearsal: both ranks on this box's one GPU."""
+    env = dict(ENV, COGS_BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg5", "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--decode-tokens", "8"], capture_output=True, text=True, timeout=1100, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["frames"] == 128 and d["config"]["frames_per_gpu"] == 64 and "replicas only" in d["config"]["parallelism"]
+    p = d["pipeline_rank0"]
+    assert p["prompt_tokens"] == 15395 and p["new_tokens"] == 8 and p["kept_visual_tokens"] == 14784
+    assert abs(d["value"] - 128 / (d["ms_per_step"] / 1e3)) < 0.01 * d["value"] and d["answers_per_s"] > 0
