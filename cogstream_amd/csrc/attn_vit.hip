@@ -36,6 +36,7 @@ struct VitAttnArgs {
     long ldq, ldk, ldv, ldo;   // elements
     const int* cu;             // [nseg + 1]
     int nseg, heads, nqb;      // grid = nseg * heads * nqb workgroups (nqb = 128-row query blocks of the longest segment)
+    int early_prefetch;        // pipe kernel prologue: tiles 1 and 2 issued before (1) / behind (0) the first wait
     int uniform_len;           // > 0: every segment has this many rows and segment s starts at row s * uniform_len (one video:
                                // all frames alike) -- the bounds are then arithmetic on kernel arguments instead of two
                                // dependent scalar loads at the head of every workgroup (700-1 700 cycles of its 39 000)
@@ -592,8 +593,15 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     PSTAMP();      // Q loads issued
 #endif
     issue_tile(0);
-    if (nt > 1) issue_tile(1);
-    if (nt > 2) issue_tile(2);
+    // round 4: only Q and tile 0 go out before the first wait (10 vector-memory instructions per wave instead of 18: the
+    // CU's vector-memory path takes one 1 KiB piece per ~60-115 cycles, so the 8 pieces of tiles 1 and 2 used to stand
+    // between every wave and its first MFMA); tiles 1 and 2 follow behind the barrier, in order, so the counted waits of
+    // the tile loop see the same queue as before. (p.early_prefetch: the old order, for A/B runs)
+    const bool EARLY = p.early_prefetch != 0;
+    if (EARLY) {
+        if (nt > 1) issue_tile(1);
+        if (nt > 2) issue_tile(2);
+    }
 #ifdef COGS_PIPE_STAMPS2
     PSTAMP();      // tiles issued
 #endif
@@ -603,6 +611,10 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     __builtin_amdgcn_s_waitcnt(0xc07f);                               // lgkmcnt(0): the constant chunks
     PSTAMP();      // 1: Q and tile 0 landed
     __builtin_amdgcn_s_barrier();
+    if (!EARLY) {
+        if (nt > 1) issue_tile(1);
+        if (nt > 2) issue_tile(2);
+    }
     f32x16 sa, sb;
     u32x4 kf[KS];                                                     // K fragments of the NEXT block to be multiplied
     if (wave_active) {
@@ -769,6 +781,8 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     if ((long)p.nseg * p.heads * p.nqb > 0x7fffffffL) return COGS_E_INVALID;
     dim3 grid(p.nseg * p.heads * p.nqb);
     static const int variant = getenv("COGS_ATTN_VIT") ? atoi(getenv("COGS_ATTN_VIT")) : 2;     // 1: unpipelined (A/B runs)
+    static const int env_early = getenv("COGS_AV_EARLY") ? atoi(getenv("COGS_AV_EARLY")) : 0;
+    p.early_prefetch = env_early;
     if (variant == 1 || a.ldk != a.ldv) hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn_vit_pipe_kernel<72>, grid, dim3(256), 0, st, p);
     return COGS_LAUNCH_CHECK();
