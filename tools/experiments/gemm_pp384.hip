@@ -1,8 +1,9 @@
 // Probe: the ping-pong body of csrc/gemm.hip (gemm_tn_pp_kernel) with a 256 x 384 tile -- a wave owns 128 x 96
 // (192 accumulator + 56 fragment registers), 40 KiB per 32-wide K-tile, 4-slot ring = all 160 KiB of LDS. Per MAC it moves
 // 0.83 of the 256 x 256 tile's bytes through the CU's vector-memory path (the resource the shipped kernel shares with the
-// MFMA pipe at about equal load), and N = 1152 / 3456 are whole multiples of 384. Plain bf16 GEMM, simple stores; timing
-// probe for tools/experiments/gemm_pp384_ab.py.
+// MFMA pipe at about equal load), and N = 1152 / 3456 are whole multiples of 384. Plain bf16 GEMM, simple stores. NEVER RUN:
+// hipcc allocates 256 VGPRs and spills 40 registers inside the MFMA segment (-Rpass-analysis=kernel-resource-usage; scratch
+// reloads count on vmcnt, which the staging waits rely on), so the probe stops at the compile.
 #include "common.h"
 #include <stdlib.h>
 #include <atomic>
