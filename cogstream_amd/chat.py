@@ -499,6 +499,27 @@ class CogReasoner:
             gcount += t
         return torch.cat(masks).bool()
 
+    def _maybe_truncate_visual_tokens(self, mm_features, compression_mask, batched_num_patches, modals, input_ids,
+                                      position_ids=None):
+        """:349-381 -- packed rows only (position_ids given, i.e. training-style packing; inference passes None and gets
+        its inputs back): when a sample's text was cut and fewer <image> placeholders survive than it has visual tokens,
+        the surplus tokens (and their mask entries) are dropped. Samples are delimited by position_ids == 0."""
+        ids = input_ids.reshape(-1).cpu()
+        if position_ids is None or mm_features.shape[0] == int((ids == self.config.image_token_index).sum()):
+            return mm_features, compression_mask
+        pos = position_ids.reshape(-1).cpu()
+        ends = [int(i) for i in torch.nonzero(pos == 0)[:, 0].tolist() if i > 0] + [int(ids.numel())]
+        starts = [0] + ends[:-1]
+        counts = [int((ids[a:b] == self.config.image_token_index).sum()) for a, b in zip(starts, ends)]
+        keep = []
+        for n_patches, modal in zip([int(x) for x in batched_num_patches.tolist()], modals):
+            keep.append(torch.ones(0 if modal == "text" else n_patches, dtype=torch.bool))
+        for n, m in zip(counts, keep):          # zip stops at the shorter list, exactly like the reference (:376-378)
+            if m.numel() > 0:
+                m[n:] = False
+        keep = torch.cat(keep).to(mm_features.device)
+        return mm_features[keep], compression_mask[keep.to(compression_mask.device)]
+
     def _compress_visual_tokens(self, compression_mask, input_ids, attention_mask):
         """:449-476 (inference subset). Returns (row index of every kept visual token, input_ids', mask')"""
         keep = compression_mask.cpu().numpy().astype(bool)
@@ -513,7 +534,7 @@ class CogReasoner:
     # ------------------------------------------------------------------ multimodal assembly
     def prepare_inputs_labels_for_multimodal(self, input_ids=None, attention_mask=None, pixel_values=None,
                                              grid_sizes=None, merge_sizes=None, modals=None, total_image_num=0,
-                                             if_visual=True, video_keys=None):
+                                             if_visual=True, video_keys=None, position_ids=None):
         """:513-584 -> (inputs_embeds [1,S',H] on the device, attention_mask [1,S'])"""
         B, N = input_ids.shape
         assert B == 1, "Token compression is only supported for batch_size=1"
@@ -536,6 +557,7 @@ class CogReasoner:
             mm = self.compress_unimportant_events(mm, mm.shape[0] // total_image_num, frame_indices)
             mask = self._get_compression_mask(pixel_values, batched, grid_sizes, merge_sizes, modals,
                                               minor_frame_indices=frame_indices)
+            mm, mask = self._maybe_truncate_visual_tokens(mm, mask, batched, modals, ids, position_ids)      # :555-562
             self.last_debug.update(minor_frames=frame_indices, compression_mask=mask)
             if self.use_token_compression:
                 rows, ids, am = self._compress_visual_tokens(mask, ids, am)

@@ -183,6 +183,29 @@ def golden_image_modality():
     save("image_modality.npz", **out)
 
 
+def golden_truncate():
+    """_maybe_truncate_visual_tokens (cogreasoner_chat.py:349-381), the reference's own method on a packed two-sample
+    row: position_ids restart at the second sample, the first sample's text was cut so that only 5 of its 8 visual
+    placeholders survive -- the surplus visual tokens (and mask entries) must go. Also the two identity cases
+    (position_ids None; counts already equal)."""
+    ns = types.SimpleNamespace(config=types.SimpleNamespace(image_token_index=IMAGE))
+    fn = ref_chat.Videollama3MetaForCausalLM._maybe_truncate_visual_tokens
+    g = torch.Generator().manual_seed(9)
+    mm = torch.randn(8 + 6, 16, generator=g)
+    mask = torch.rand(14, generator=g) > 0.3
+    batched = torch.tensor([8, 6])
+    modals = ["video", "image"]
+    ids = torch.tensor([1, 2] + [IMAGE] * 5 + [3, 4] + [7] + [IMAGE] * 6 + [9])
+    pos = torch.tensor(list(range(9)) + list(range(8)))
+    out_mm, out_mask = fn(ns, mm, mask, batched, modals, ids, pos)
+    same_mm, same_mask = fn(ns, mm, mask, batched, modals, ids, None)
+    ids_full = torch.tensor([1] + [IMAGE] * 8 + [2] + [IMAGE] * 6)
+    eq_mm, eq_mask = fn(ns, mm, mask, batched, modals, ids_full, torch.arange(16))
+    assert same_mm is mm and eq_mm is mm
+    save("truncate.npz", mm=mm, mask=mask, batched=batched, input_ids=ids, position_ids=pos, out_mm=out_mm, out_mask=out_mask,
+         input_ids_full=ids_full)
+
+
 def golden_kmeans():
     cases = {}
     for ci, (T, P, D, K, seed) in enumerate([(150, 3, 16, 10, 0), (64, 2, 8, 5, 1), (40, 1, 32, 6, 2), (6, 2, 4, 8, 3)]):
@@ -981,7 +1004,7 @@ if __name__ == "__main__":
     if "--only-preprocess" in sys.argv:
         golden_preprocess()
         sys.exit(0)
-    which = sys.argv[1:] or ["preprocess", "vit", "vit_bf16", "kmeans", "kmeans_reseed", "compress", "text", "e2e", "e2e_blockdiag", "qwen2", "lora", "image_modality"]
+    which = sys.argv[1:] or ["preprocess", "vit", "vit_bf16", "kmeans", "kmeans_reseed", "compress", "text", "e2e", "e2e_blockdiag", "qwen2", "lora", "image_modality", "truncate"]
     with torch.no_grad():
         for w in which:
             globals()["golden_" + w]()

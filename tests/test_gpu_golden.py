@@ -726,3 +726,20 @@ def test_kmeans_margin_statistics_flag_the_planted_near_ties(dev):
     torch.manual_seed(0)
     km.kmeans_with_time_min_max(sep, torch.zeros(120), 6)
     assert km.last_stats["rows_below_1e-3"] == 0 and km.last_stats["min_rel_margin"] > 1e-3
+
+
+def test_maybe_truncate_visual_tokens_vs_reference(dev):
+    """_maybe_truncate_visual_tokens (cogreasoner_chat.py:349-381; tests/golden/truncate.npz made by the reference's own
+    method): a packed row whose first sample kept 5 of its 8 <image> placeholders loses the 3 surplus visual tokens and
+    mask entries; without position_ids, or when the counts already agree, the inputs come back untouched"""
+    g = _load("truncate.npz")
+    model = _tiny_model(dev, torch.float32, 0)
+    model.config.image_token_index = 258
+    mm, mask = torch.from_numpy(g["mm"]).to(dev), torch.from_numpy(g["mask"]).to(dev)
+    batched, ids, pos = torch.from_numpy(g["batched"]), torch.from_numpy(g["input_ids"]), torch.from_numpy(g["position_ids"])
+    out_mm, out_mask = model._maybe_truncate_visual_tokens(mm, mask, batched, ["video", "image"], ids, pos)
+    assert torch.equal(out_mm.cpu(), torch.from_numpy(g["out_mm"])) and torch.equal(out_mask.cpu(), torch.from_numpy(g["out_mask"]))
+    a, b = model._maybe_truncate_visual_tokens(mm, mask, batched, ["video", "image"], ids, None)
+    assert a is mm and b is mask
+    a, b = model._maybe_truncate_visual_tokens(mm, mask, batched, ["video", "image"], torch.from_numpy(g["input_ids_full"]), torch.arange(16))
+    assert a is mm and b is mask
