@@ -100,7 +100,7 @@ def _disassemble(obj: Path, tag: str) -> str:
             f.unlink()
 
 
-def check_m0_uses(obj: Path):
+def check_m0_uses(obj: Path, kernel: str = "attn_vit_pipe_kernel"):
     """csrc/attn_vit.hip issues its LDS-DMA pieces from inline asm that writes M0 (`s_mov_b32 m0, sN` right in front of
     `global_load_lds_dwordx4`) without naming M0 as clobbered (hipcc warns about the clobber and never keeps a value in
     M0 across statements). That assumption is checked here instead: inside attn_vit_pipe_kernel every instruction that
@@ -110,7 +110,7 @@ def check_m0_uses(obj: Path):
     for line in _disassemble(obj, "m0_check").splitlines():
         m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
         if m:
-            inside = "attn_vit_pipe_kernel" in m.group(1)
+            inside = kernel in m.group(1)
             continue
         ins = line.split("//")[0].strip()
         if inside and re.search(r"\bm0\b", ins) and not re.match(r"^s_mov_b32 m0, s\d+$", ins):
@@ -186,6 +186,21 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                                "(csrc/attn_vit.hip, dma16): " + "; ".join(m0_bad[:6]))
         if m0_bad is not None:
             m0_stamp.write_text("ok: every m0 reference inside attn_vit_pipe_kernel is an inline-asm s_mov_b32 m0, sN\n")
+    # the same inline-asm LDS-DMA in the Qwen2 prompt attention (csrc/attn.hip, attn_prefill_dma_kernel)
+    attn2_o, m0_stamp2 = OBJ / "attn.o", OBJ / "attn.m0_check.txt"
+    if not m0_stamp2.exists() or m0_stamp2.stat().st_mtime < attn2_o.stat().st_mtime:
+        try:
+            m0_bad = check_m0_uses(attn2_o, "attn_prefill_dma_kernel")
+        except (OSError, RuntimeError) as e:
+            if strict:
+                raise
+            print(f"WARNING: M0 check of attn.o not possible ({e})", flush=True)
+            m0_bad = None
+        if m0_bad:
+            raise RuntimeError("attn_prefill_dma_kernel: hipcc generated its own uses of M0 beside the inline-asm LDS-DMA "
+                               "(csrc/attn.hip, dma16): " + "; ".join(m0_bad[:6]))
+        if m0_bad is not None:
+            m0_stamp2.write_text("ok: every m0 reference inside attn_prefill_dma_kernel is an inline-asm s_mov_b32 m0, sN\n")
     objs = [OBJ / (s.stem + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB)] + [str(o) for o in objs]

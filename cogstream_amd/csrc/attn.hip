@@ -488,6 +488,286 @@ __global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : ((PRE && HD == 72) ? 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Qwen2 prompt attention (hd 128, causal, GQA, pre-scaled Q, one or several sequences): the kernel above with the K/V
+// staging taken out of the registers. Same products, same deferred-max softmax, same masks -- what changes is how a
+// tile gets into LDS and how often the workgroup synchronises:
+//   * K/V tiles go global -> LDS by global_load_lds_dwordx4 (eight 1 KiB pieces per wave and tile, no staging
+//     registers, no ds_write, no load -> write dependency) into a DOUBLE buffer, one tile ahead, ONE barrier per tile
+//     (the kernel above: one buffer, two barriers, 8 global loads + 8 ds_write_b128 per thread and tile);
+//   * LDS-DMA writes a piece as the plain image of its lanes (lane L -> bytes 16 L .. 16 L + 15), so the bank swizzles
+//     live on the SOURCE address: K keeps the chunk XOR of the kernel above (lane L of a piece fetches chunk
+//     (L & 15) ^ k_swz(row)); V rows are 256 contiguous bytes with their own chunk XOR (v_swz: the eight (row & 3,
+//     row bit 3) classes a 32-lane half of a transposing read touches land in eight different 32-byte bank groups);
+//   * rows past the end of the key range are fetched from its last row (finite data: their scores are masked, their
+//     probabilities exactly zero) instead of being zero filled.
+// The DMA is issued from inline assembly for the reason given in attn_vit.hip (hipcc's wait insertion would drain the
+// prefetch in front of every transposing read); cogstream_amd/build.py checks that nothing else in the kernel touches M0.
+__device__ __forceinline__ int v_swz(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
+
+__global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
+    constexpr int HD = 128, NQ = 2, NT = 256, KS = 4, DT = 8;
+    constexpr int K_LDS = 64 * 256, V_LDS = 64 * 256, BUF = K_LDS + V_LDS;     // 32 KiB per tile
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int seg = blockIdx.z;
+    const int gsz = p.hq / p.hkv;
+    const int kvh = blockIdx.y / gsz;
+
+    int qs = 0, qe = p.q_len, ks = 0, ke = p.kv_len;
+    if (p.cu) { qs = p.cu[seg]; qe = p.cu[seg + 1]; ks = qs; ke = qe; }
+    const int qt = p.heavy_first ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int q0 = qs + qt * 128;
+    if (q0 >= qe) return;
+
+    const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q);
+    const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K);
+    const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.V);
+
+    bf16x8 qf[NQ][KS];
+    int qrow[NQ];
+    bool qok[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        qrow[qi] = q0 + wid * 32 + qi * 16 + li;
+        qok[qi] = qrow[qi] < qe;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 v = {0, 0, 0, 0};
+            if (qok[qi]) v = *reinterpret_cast<const u32x4*>(Qp + (long)qrow[qi] * p.ldq + blockIdx.y * HD + 32 * s + 8 * g);
+            qf[qi][s] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    const int kend = min(ke, ks + (q0 - qs) + 127 + p.q_pos0 + 1);      // causal
+    const int nt = (kend - ks + 63) / 64;
+
+    f32x4 oacc[DT][NQ];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) oacc[d][qi] = f32x4{0, 0, 0, 0};
+    float l_run[NQ], m_ref[NQ];
+    bool first_tile = true;
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) { l_run[qi] = 0.f; m_ref[qi] = 0.f; }
+
+    // ---- staging by LDS-DMA: wave w issues pieces w, w + 4, w + 8, w + 12 (4 tile rows each) of K and of V
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    int st_row[4], k_off[4], v_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * (wid + 4 * i) + (lane >> 4);
+        st_row[i] = row;
+        k_off[i] = (row * (int)p.ldk + kvh * HD + ((lane & 15) ^ k_swz(row)) * 8) * 2;     // bytes from the tile's first row
+        v_off[i] = (row * (int)p.ldv + kvh * HD + ((lane & 15) ^ v_swz(row)) * 8) * 2;
+    }
+    auto uniform_ptr = [](const bf16_t* q) -> const bf16_t* {
+        const unsigned long long v = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const bf16_t*)(((unsigned long long)hi << 32) | lo);
+    };
+    auto dma16 = [&](const bf16_t* base, int off_bytes, unsigned lds) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(lds), "v"(off_bytes), "s"(base) : "memory");
+    };
+    auto issue_tile = [&](int kt) {
+        const int kbase = ks + kt * 64;
+        const int valid = ke - kbase;                               // >= 1
+        const bf16_t* kb = uniform_ptr(Kp + (long)kbase * p.ldk);
+        const bf16_t* vb = uniform_ptr(Vp + (long)kbase * p.ldv);
+        const unsigned st = __builtin_amdgcn_readfirstlane(smem_lds + (kt & 1) * BUF);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ko = k_off[i], vo = v_off[i];
+            if (valid < 64) {                                        // rows past the key range repeat its last row
+                const int back = st_row[i] - min(st_row[i], valid - 1);
+                ko -= back * (int)p.ldk * 2;
+                vo -= back * (int)p.ldv * 2;
+            }
+            dma16(kb, ko, st + (wid + 4 * i) * 1024);
+            dma16(vb, vo, st + K_LDS + (wid + 4 * i) * 1024);
+        }
+    };
+
+    // per-lane LDS read addressing
+    const int krow0 = 8 * (li >> 2) + (li & 3);
+    // V transposed read of (u, d): 16-lane group g reads rows 32u + 8g + (li >> 2) [+4], bytes 32 d + 8 (li & 3) .. +7
+    const int vr = 8 * g + (li >> 2);                 // + 32u (+4): v_swz is the same for all of them (bits 0, 1, 3 of vr)
+    const int v_sw = v_swz(vr);
+    const int v_base = vr * 256 + ((li & 3) & 1) * 8;   // + 32u*256 (+4*256) + (((2d + ((li&3)>>1)) ^ v_sw) << 4)
+    const int v_ch = (li & 3) >> 1;
+
+    const bool wave_active = q0 + wid * 32 < qe;
+
+    auto process_tile = [&](const int kt, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const char* Ks = smem + (kt & 1) * BUF;
+        const char* Vs = Ks + K_LDS;
+        if (!wave_active) return;
+        const int kbase = ks + kt * 64;
+        const bool second_half = !MASKED || kbase + 32 < kend;
+        f32x4 sacc[4][NQ];
+#pragma unroll
+        for (int ut = 0; ut < 4; ++ut) {
+            if (MASKED && ut >= 2 && !second_half) {
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) sacc[ut][qi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
+            const int krow = 32 * (ut >> 1) + 4 * (ut & 1) + krow0;
+            const int ksw = k_swz(krow);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + krow * 256 + (((4 * s + g) ^ ksw) << 4));
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    const float nm = -m_ref[qi];
+                    const f32x4 c0 = f32x4{nm, nm, nm, nm};
+                    sacc[ut][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, kf), qf[qi][s], s == 0 ? c0 : sacc[ut][qi], 0, 0, 0);
+                }
+            }
+        }
+        bf16x8 pf[2][NQ];
+        float post_alpha[NQ];
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            float sv[4][4];
+            post_alpha[qi] = 1.f;
+            float d = -INFINITY;
+            if constexpr (MASKED) {
+                const int qloc = qrow[qi] - qs;
+#pragma unroll
+                for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kbase + 32 * (ut >> 1) + 8 * g + 4 * (ut & 1) + r;
+                        const bool valid = key < ke && (key - ks) <= qloc + p.q_pos0;
+                        const float sc = valid ? sacc[ut][qi][r] : -INFINITY;
+                        sv[ut][r] = sc;
+                        d = fmaxf(d, sc);
+                    }
+            } else {
+#pragma unroll
+                for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sv[ut][r] = sacc[ut][qi][r]; d = fmaxf(d, sacc[ut][qi][r]); }
+            }
+            d = colgroup_max(d);
+            if (first_tile) {
+                const float d0 = (d == -INFINITY) ? 0.f : d;
+#pragma unroll
+                for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sv[ut][r] -= d0;
+                asm volatile("" ::: "memory");
+                m_ref[qi] = d0;
+                d = 0.f;
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int ut = 0; ut < 4; ++ut)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(sv[ut][r]);
+                    sv[ut][r] = pv;
+                    psum += pv;
+                }
+            l_run[qi] += psum;
+            if (__any(d > 0.f)) {
+                const float dd = fmaxf(d, 0.f);
+                post_alpha[qi] = __builtin_amdgcn_exp2f(-dd);
+                m_ref[qi] += dd;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                u32x4 w;
+                w[0] = pack_bf2(sv[2 * u][0], sv[2 * u][1]);
+                w[1] = pack_bf2(sv[2 * u][2], sv[2 * u][3]);
+                w[2] = pack_bf2(sv[2 * u + 1][0], sv[2 * u + 1][1]);
+                w[3] = pack_bf2(sv[2 * u + 1][2], sv[2 * u + 1][3]);
+                pf[u][qi] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (MASKED && u == 1 && !second_half) continue;
+                const char* va = Vs + u * 32 * 256 + v_base + ((((2 * d + v_ch) ^ v_sw)) << 4);
+                const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va));
+                const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + 4 * 256));
+                u32x4 w;
+                u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                w[0] = l2[0]; w[1] = l2[1]; w[2] = h2[0]; w[3] = h2[1];
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi)
+                    oacc[d][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][qi], oacc[d][qi], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            if (__any(post_alpha[qi] != 1.f)) {
+                l_run[qi] *= post_alpha[qi];
+#pragma unroll
+                for (int d = 0; d < DT; ++d) oacc[d][qi] *= post_alpha[qi];
+            }
+        }
+        first_tile = false;
+    };
+
+    // leading tiles [0, t_mid) need no mask: fully inside the key range and left of the causal diagonal
+    int t_mid;
+    {
+        int full = (ke - ks) / 64;
+        const int lim = (q0 - qs) + p.q_pos0 - 63;
+        full = min(full, lim >= 0 ? lim / 64 + 1 : 0);
+        t_mid = max(0, min(full, nt));
+    }
+    issue_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[qi][s]));     // Q loads complete before the loop
+    __builtin_amdgcn_s_barrier();
+    auto tile_tail = [&](int kt) {
+        // tile kt + 1 (issued at the top of this iteration) has landed for this wave; after the barrier for every wave,
+        // and nobody reads tile kt's buffer any more -- it is the one tile kt + 2 goes into
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int kt = 0; kt < t_mid; ++kt) {
+        if (kt + 1 < nt) issue_tile(kt + 1);
+        process_tile(kt, std::false_type{});
+        tile_tail(kt);
+    }
+    for (int kt = t_mid; kt < nt; ++kt) {
+        if (kt + 1 < nt) issue_tile(kt + 1);
+        process_tile(kt, std::true_type{});
+        tile_tail(kt);
+    }
+
+    bf16_t* Op = reinterpret_cast<bf16_t*>(p.O);
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        float l = l_run[qi];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (!qok[qi]) continue;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            f32x4 v = oacc[d][qi] * inv;
+            st4_f<bf16_t>(Op + (long)qrow[qi] * p.ldo + blockIdx.y * HD + 16 * d + 4 * g, v);
+        }
+    }
+}
+
 // combine the key-split partials: one 256-thread block per (query row, head). The split weights are computed
 // once (thread s owns split s), then the [nsplit, HD] partial rows are summed with independent loads:
 // 256/HDP split-groups run in parallel and meet in LDS.
@@ -660,7 +940,11 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
     } while (0)
         // the generated tokens' attention (one query row, key-split) has its own kernel: every wave owns whole tiles
         static const bool env_old_dec = getenv("COGS_ATTN_DECODE") && atoi(getenv("COGS_ATTN_DECODE")) == 0;   // A/B runs only
-        if (a.head_dim == 128 && a.q_len == 1 && p.nsplit > 1 && p.gqa_pack && pre && !env_old_dec) {
+        static const bool env_no_dma = getenv("COGS_ATTN_PREFILL_DMA") && atoi(getenv("COGS_ATTN_PREFILL_DMA")) == 0;   // A/B runs only
+        if (a.head_dim == 128 && pre && a.causal && p.nsplit == 1 && !p.gqa_pack && !a.row_lo && !env_no_dma && a.q_len >= 128 &&
+            a.ldo % 8 == 0) {
+            hipLaunchKernelGGL(attn_prefill_dma_kernel, grid, dim3(256), 0, st, p);
+        } else if (a.head_dim == 128 && a.q_len == 1 && p.nsplit > 1 && p.gqa_pack && pre && !env_old_dec) {
             const int rc = cogs_k_attention_decode(st, a, p.part_o, p.part_ml);
             if (rc != COGS_OK) return rc;
         } else if (a.head_dim == 72) {
