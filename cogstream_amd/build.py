@@ -56,7 +56,7 @@ def check_epilogue_vmem_counts(obj: Path):
     for line in dis_text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
         if m:
-            k = re.search(r"gemm_tn_pp_kernelILi(\d+)E", m.group(1))
+            k = re.search(r"gemm_tn_pp(?:64)?_kernelILi(\d+)E", m.group(1))
             kern_epi, state = (int(k.group(1)) if k else None), None
             continue
         if kern_epi is None:

@@ -600,6 +600,244 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
 }
 
+// ---------------------------------------------------------------------------------------------
+// Whole-line staging for the ping-pong kernel (round 4). The kernel above stages 32-wide K-tiles: an LDS-DMA piece is 16
+// rows x 64 B, i.e. sixteen HALF 128-byte lines per wave instruction, and the CU's vector-memory path takes such pieces at
+// 29-30 B/clk against 54-55 B/clk for pieces made of whole lines (tools/micro/ldsdma_rate.cpp, L2-resident rows, 8 waves
+// per CU) -- at 30 B/clk a 256x256 tile's staging (32 KiB per 32-wide K-tile) costs as many cycles as its 1 024 cycles of
+// MFMA. Here a piece is 8 rows x 128 B: the K stream is cut into 64-wide slabs (128-byte LDS rows, chunk ^= row & 7).
+// Same wave layout, same two segments per 32-wide half of a slab (12 fragment reads | 32 MFMAs), group 1 one barrier
+// behind group 0, so every output element sees the same MFMAs in the same order as in the kernel above (bit-identical
+// results). LDS: a slab is two 32 KiB units, its 256 A rows and its 256 W rows; the ring holds FIVE units (all 160 KiB,
+// so the rotary LUT variant stays with the kernel above) in the order A0 W0 A1 W1 A2 ...: while slab s is consumed, A(s),
+// W(s), A(s+1) are resident or landing and the two positions slab s-1 left take W(s+1) -- issued in the FIRST load segment
+// of slab s -- and A(s+2) -- issued in the SECOND. Every wave issues 4 pieces per load segment, so each of a slab's four
+// intervals carries 16 pieces, as in the kernel above, but of whole lines. One counted vmcnt per slab: behind the units a
+// slab needs, each wave has issued 12 newer pieces (A(s+2), W(s+2), A(s+3)), plus, across a tile boundary, the epilogue's
+// loads and stores (exact-count rule as above, else a stricter count that waits for them too).
+constexpr int ROW4 = 128;                         // bytes per LDS row = 64 bf16 = one line of the operand
+constexpr int UNIT4 = 256 * ROW4;                 // 32 KiB: the A rows or the W rows of one slab
+constexpr int RING4 = 5;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert((EPI & EPI_ROPE_LUT) == 0, "no LDS left for the rotary LUT");
+    typedef bf16_t T;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2;          // 0: rows 0..127 of the tile, 1: rows 128..255; also the stagger group
+    const int wc = wid & 3;
+    const int nb = p.nbm * p.nbn;
+    const int KS = p.K / 64;
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int xcd = t & 7, q = nb >> 3, r = nb & 7;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+        const int per_group = p.group_m * p.nbn;
+        const int first_m = (bid / per_group) * p.group_m;
+        const int gsz = min(p.nbm - first_m, p.group_m);
+        m0 = (first_m + (bid % per_group) % gsz) * BM3;
+        n0 = ((bid % per_group) / gsz) * BN3;
+    };
+
+    // staging: a unit is 32 pieces of 1 KiB (8 rows x 128 B); wave w owns pieces 4w..4w+3 of EVERY unit (rows 32w..32w+31).
+    // lane -> row lane>>3 of the piece, LDS chunk lane&7, source chunk (lane&7) ^ (row&7). Addresses: a uniform base
+    // (operand + first row of the tile + K offset) + a 32-bit lane offset. The A and the W stream advance separately (the
+    // A stream runs a unit ahead of the W stream and may already be in the next tile).
+    unsigned long long base_a = 0, base_w = 0;
+    int voff_a[4], voff_w[4];
+    int sa_t = blockIdx.x, sa_ks = 0, sw_t = blockIdx.x, sw_ks = 0;
+    auto set_src_a = [&](int t) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+        base_a = (unsigned long long)p.A + (unsigned long long)m0 * p.lda;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = m0 + wid * 32 + i * 8 + (lane >> 3);
+            voff_a[i] = (min(r, p.M - 1) - m0) * (int)p.lda + (((lane & 7) ^ (lane >> 3)) << 4);
+        }
+    };
+    auto set_src_w = [&](int t) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+        base_w = (unsigned long long)p.W + (unsigned long long)n0 * p.ldw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = n0 + wid * 32 + i * 8 + (lane >> 3);
+            voff_w[i] = (min(r, p.N - 1) - n0) * (int)p.ldw + (((lane & 7) ^ (lane >> 3)) << 4);
+        }
+    };
+    const unsigned lds_wave = smem_lds + wid * 4096;
+    int ipos = 0;                                    // ring position of the next unit to issue
+    auto issue4 = [&](unsigned long long b, const int (&voff)[4]) {
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b), bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        const char* bp = (const char*)(((unsigned long long)bhi << 32) | blo);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave + ipos * UNIT4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(dst + i * 1024), "v"(voff[i]), "s"(bp) : "memory");
+        ipos = ipos + 1 == RING4 ? 0 : ipos + 1;
+    };
+    auto issue_a = [&]() {
+        if (sa_t >= nb) return;
+        issue4(base_a + (unsigned long long)sa_ks * ROW4, voff_a);
+        if (++sa_ks == KS) {
+            sa_ks = 0;
+            sa_t += gridDim.x;
+            if (sa_t < nb) set_src_a(sa_t);
+        }
+    };
+    auto issue_w = [&]() {
+        if (sw_t >= nb) return;
+        issue4(base_w + (unsigned long long)sw_ks * ROW4, voff_w);
+        if (++sw_ks == KS) {
+            sw_ks = 0;
+            sw_t += gridDim.x;
+            if (sw_t < nb) set_src_w(sw_t);
+        }
+    };
+
+    // fragment read offsets inside a unit: row r = lane&15, k-chunk (lane>>4) of the slab's first half; the second half is ^ 64
+    const int foff = (lane & 15) * ROW4 + (((lane >> 4) ^ (lane & 7)) << 4);
+    const int a_off = (grp * 128) * ROW4 + foff;                 // + 64*ROW4 + mi*16*ROW4
+    const int w_off = (wc * 64) * ROW4 + foff;                   // + ni*16*ROW4
+
+    f32x4 acc[2][4][4];
+    u32x4 afr[4], afr2[4], wfr[4];
+
+    if (sa_t >= nb) return;
+    set_src_a(sa_t);
+    set_src_w(sw_t);
+    const int my_tiles = (nb - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    const int total = my_tiles * KS;          // slabs this workgroup consumes
+    // prologue: A0 W0 A1 in flight, slab 0 landed (a stream that has run out issues nothing)
+    issue_a(); issue_w(); issue_a();
+    if (total >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+
+    int epi_ops = 0;       // vector-memory instructions of the previous tile's epilogue when known exactly, else 0
+    constexpr int PAIR_OK = (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0;
+    constexpr int OPS_A = epi_pair_vmem_ops<EPI>();                                   // rotary / plain tile
+    constexpr int OPS_B = epi_pair_vmem_ops<(EPI & ~(EPI_ROPE | EPI_ROPE_LUT))>();    // tile right of rope_cols
+    // Slab g+1 = A(g+1), W(g+1) has landed when at most the 4 pieces of A(g+2) -- the only unit a wave issues after
+    // W(g+1) -- are outstanding. Across a tile boundary W(g+1) goes out in FRONT of the previous tile's epilogue, whose
+    // loads and stores are then newer than it and may stay in flight too when their number is known exactly.
+    bool pre_issued = false;
+    auto wait_next_slab = [&](int g, bool after_epilogue) {
+        const bool a2 = 2 * g + 4 <= 2 * total - 1;                   // A(g+2) exists
+        if (after_epilogue) {
+            if (PAIR_OK && epi_ops != 0 && a2) {
+                constexpr int WAIT_A = 4 + OPS_A < 63 ? 4 + OPS_A : 63;
+                constexpr int WAIT_B = 4 + OPS_B < 63 ? 4 + OPS_B : 63;
+                if (epi_ops == OPS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_A) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_B) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            return;
+        }
+        if (a2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    int ra = 0, rw = 1;    // ring positions of the current slab's A and W unit
+    int g = 0;             // index of the slab being consumed (0..total-1)
+    for (int t = blockIdx.x; t < nb; t += gridDim.x) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef COGS_GEMM_KSTAMPS
+        // diagnostic build only: where does a slab's time go? sums over the slabs of this tile, per wave group
+        unsigned long long ks_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long ks_prev = __builtin_amdgcn_s_memtime();
+#define KSTAMP4(i_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ks_sum[i_] += now_ - ks_prev; ks_prev = now_; } while (0)
+#else
+#define KSTAMP4(i_) do {} while (0)
+#endif
+        for (int ks = 0; ks < KS; ++ks, ++g) {
+            const char* ua = smem + ra * UNIT4;
+            const char* uw = smem + rw * UNIT4;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int ao = a_off ^ (half << 6), wo = w_off ^ (half << 6);   // k-chunk index ^ 4
+                // ---- L segment: 12 fragment reads and this wave's 4 pieces of W(g+1) (first half) / A(g+2) (second) ----
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wfr[i] = *reinterpret_cast<const u32x4*>(uw + wo + i * 16 * ROW4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) afr[i] = *reinterpret_cast<const u32x4*>(ua + ao + i * 16 * ROW4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) afr2[i] = *reinterpret_cast<const u32x4*>(ua + ao + 64 * ROW4 + i * 16 * ROW4);
+                // W(g+1) -> position of A(g-1), A(g+2) -> position of W(g-1): both groups drained their reads of slab
+                // g-1 (lgkmcnt(0)) before the barrier that opened this slab's first interval (WAR safe)
+                if (half == 1) issue_a();
+                else if (!pre_issued) issue_w();
+                if (half == 0) pre_issued = false;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(afr[0]), "+v"(afr[1]), "+v"(afr[2]), "+v"(afr[3]), "+v"(wfr[0]), "+v"(wfr[1]),
+                             "+v"(wfr[2]), "+v"(wfr[3]));
+                asm volatile("" : "+v"(afr2[0]), "+v"(afr2[1]), "+v"(afr2[2]), "+v"(afr2[3]));
+                if (half == 1 && grp == 1) wait_next_slab(g, ks == 0 && g > 0);
+                KSTAMP4(half * 4 + 0);
+                __builtin_amdgcn_s_barrier();
+                KSTAMP4(half * 4 + 1);
+                // ---- C segment: 32 MFMAs ----
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[0][mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr2[mi]), acc[1][mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (half == 1 && grp == 0) wait_next_slab(g, ks == 0 && g > 0);
+                KSTAMP4(half * 4 + 2);
+                __builtin_amdgcn_s_barrier();
+                KSTAMP4(half * 4 + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(0);
+                asm volatile("" ::: "memory");
+            }
+            ra = ra + 2 >= RING4 ? ra + 2 - RING4 : ra + 2;
+            rw = rw + 2 >= RING4 ? rw + 2 - RING4 : rw + 2;
+        }
+#ifdef COGS_GEMM_KSTAMPS
+        if (p.trace && blockIdx.x == 0 && wc == 0 && lane == 0 && t == (int)blockIdx.x) {   // first tile of workgroup 0
+            unsigned long long* o = p.trace + 192 + grp * 8;
+            for (int i = 0; i < 8; ++i) o[i] = ks_sum[i];
+        }
+#endif
+        // W of the next tile's second slab goes out in front of the epilogue (into the position of this tile's last A
+        // unit: both groups drained their reads of it before the barrier above). The epilogue runs inside this group's
+        // next L interval, i.e. beside the other group's C.
+        issue_w();
+        pre_issued = true;
+        const int ops = epilogue_wave_pair<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0], acc[1]);
+#ifdef COGS_EPI_CONSERVATIVE
+        epi_ops = 0; (void)ops;
+#else
+        epi_ops = ops > 0 ? ops : 0;
+#endif
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
+}
+
 }  // namespace
 
 // kernel launches issued by cogs_k_gemm on this thread (a round-aligned split is two): lets the profiler bracket
@@ -641,6 +879,17 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         (void)hipMemsetAsync(dbuf, 0, 208 * 8, st);
         GemmArgs q = p;
         q.trace = dbuf;
+        static const bool env_pp64t = getenv("COGS_GEMM_PP64") && atoi(getenv("COGS_GEMM_PP64")) != 0;
+        bool done64 = false;
+        if constexpr ((EPI & EPI_ROPE_LUT) == 0) {
+            if (env_pp64t) {
+                static std::atomic<uint64_t> attr_done64t{0};
+                cogs_ensure_dyn_lds((const void*)gemm_tn_pp64_kernel<EPI>, RING4 * UNIT4, attr_done64t);
+                hipLaunchKernelGGL((gemm_tn_pp64_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), RING4 * UNIT4, st, q);
+                done64 = true;
+            }
+        }
+        if (!done64)
         hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, q);
         unsigned long long h[208];
         (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, st);
@@ -656,6 +905,11 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         for (int g = 0; g < 2; ++g) {
             const unsigned long long* o = h + 192 + g * 8;
             const double kt_n = p.K / 32.0;
+            if (env_pp64t && (EPI & EPI_ROPE_LUT) == 0)
+                fprintf(stderr, "[gemm kstamps] group %d per 64-wide slab: L0 %.0f wait %.0f C0 %.0f wait %.0f | L1 %.0f wait %.0f C1 %.0f wait %.0f\n",
+                        g, o[0] / (kt_n / 2), o[1] / (kt_n / 2), o[2] / (kt_n / 2), o[3] / (kt_n / 2), o[4] / (kt_n / 2),
+                        o[5] / (kt_n / 2), o[6] / (kt_n / 2), o[7] / (kt_n / 2));
+            else
             fprintf(stderr, "[gemm kstamps] group %d per K-tile: L %.0f wait %.0f C %.0f wait %.0f\n",
                     g, o[0] / kt_n, o[1] / kt_n, o[2] / kt_n, o[3] / kt_n);
         }
@@ -663,6 +917,15 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         return;
     }
     ++g_gemm_launches;
+    static const bool env_pp64 = getenv("COGS_GEMM_PP64") && atoi(getenv("COGS_GEMM_PP64")) != 0;   // A/B runs
+    if constexpr ((EPI & EPI_ROPE_LUT) == 0) {
+        if (env_pp64) {
+            static std::atomic<uint64_t> attr_done64{0};
+            cogs_ensure_dyn_lds((const void*)gemm_tn_pp64_kernel<EPI>, RING4 * UNIT4, attr_done64);
+            hipLaunchKernelGGL((gemm_tn_pp64_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), RING4 * UNIT4, st, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, p);
 }
 void dispatch_pp(hipStream_t st, const GemmArgs& p, int grid, int mask) {

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogstream_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
+torch.manual_seed(0)
 bf = torch.bfloat16
 shapes = [("vit qkv", 59136, 3456, 1152), ("vit o", 59136, 1152, 1152), ("vit fc1", 59136, 4352, 1152),
           ("vit fc2", 59136, 1152, 4352), ("llm qkv", 15396, 4608, 3584), ("llm o", 15396, 3584, 3584),
@@ -39,5 +40,8 @@ for r in range(6):
 for name, a, w, out, fl in prep:
     lib = sorted(t_lib[name])[len(t_lib[name]) // 2]
     own = sorted(t_own[name])[len(t_own[name]) // 2]
+    ops.gemm(a, w, out=out)
+    digest = int(out.view(torch.int16).to(torch.int64).mul_(torch.arange(1, out.numel() + 1, device=dev).view_as(out) % 8191).sum())
+    print(f"{name:12s} digest {digest:x}")     # equal digests across runs (COGS_GEMM_* A/B builds) = bit-identical outputs
     print(f"{name:12s} M{a.shape[0]} N{w.shape[0]} K{a.shape[1]}: library {lib:7.3f} ms {fl / lib / 1e9:7.1f} TFLOP/s | cogs_gemm {own:7.3f} ms "
           f"{fl / own / 1e9:7.1f} TFLOP/s | cogs/library time {own / lib:5.2f}")
