@@ -201,6 +201,20 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                                "(csrc/attn.hip, dma16): " + "; ".join(m0_bad[:6]))
         if m0_bad is not None:
             m0_stamp2.write_text("ok: every m0 reference inside attn_prefill_dma_kernel is an inline-asm s_mov_b32 m0, sN\n")
+    m0_stamp3 = OBJ / "gemm.m0_check.txt"
+    if not m0_stamp3.exists() or m0_stamp3.stat().st_mtime < gemm_o.stat().st_mtime:
+        try:
+            m0_bad = check_m0_uses(gemm_o, "gemm_tn_pp64_kernel")
+        except (OSError, RuntimeError) as e:
+            if strict:
+                raise
+            print(f"WARNING: M0 check of gemm.o not possible ({e})", flush=True)
+            m0_bad = None
+        if m0_bad:
+            raise RuntimeError("gemm_tn_pp64_kernel: hipcc generated its own uses of M0 beside the inline-asm LDS-DMA "
+                               "(csrc/gemm.hip, issue4): " + "; ".join(m0_bad[:6]))
+        if m0_bad is not None:
+            m0_stamp3.write_text("ok: every m0 reference inside gemm_tn_pp64_kernel is an inline-asm s_mov_b32 m0, sN\n")
     objs = [OBJ / (s.stem + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB)] + [str(o) for o in objs]

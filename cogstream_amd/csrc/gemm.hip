@@ -729,24 +729,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
     // W(g+1) -- are outstanding. Across a tile boundary W(g+1) goes out in FRONT of the previous tile's epilogue, whose
     // loads and stores are then newer than it and may stay in flight too when their number is known exactly.
     bool pre_issued = false;
-    auto wait_next_slab = [&](int g, bool after_epilogue) {
+    auto wait_mode = [&](int g, bool after_epilogue) -> int {      // 0: vmcnt(0), 1: vmcnt(4), 2: 4 + OPS_A, 3: 4 + OPS_B
         const bool a2 = 2 * g + 4 <= 2 * total - 1;                   // A(g+2) exists
-        if (after_epilogue) {
-            if (PAIR_OK && epi_ops != 0 && a2) {
-                constexpr int WAIT_A = 4 + OPS_A < 63 ? 4 + OPS_A : 63;
-                constexpr int WAIT_B = 4 + OPS_B < 63 ? 4 + OPS_B : 63;
-                if (epi_ops == OPS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_A) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_B) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            return;
-        }
-        if (a2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int m = a2 ? 1 : 0;
+        if (after_epilogue) m = (PAIR_OK && epi_ops != 0 && a2) ? (epi_ops == OPS_A ? 2 : 3) : 0;
+        return m;
+    };
+    auto wait_next_slab = [&](int mode) {
+        constexpr int WAIT_A = 4 + OPS_A < 63 ? 4 + OPS_A : 63;
+        constexpr int WAIT_B = 4 + OPS_B < 63 ? 4 + OPS_B : 63;
+        if (mode == 4) return;          // the other group's turn to wait
+        if (mode == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (mode == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (mode == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_A) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_B) : "memory");
     };
 
     int ra = 0, rw = 1;    // ring positions of the current slab's A and W unit
+    int is_g1;             // scalar copy of grp (kept out of the compiler's lane-mask booleans)
+    asm volatile("s_mov_b32 %0, %1" : "=s"(is_g1) : "s"(grp));
     int g = 0;             // index of the slab being consumed (0..total-1)
     for (int t = blockIdx.x; t < nb; t += gridDim.x) {
         int m0, n0;
@@ -759,15 +760,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
                 for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef COGS_GEMM_KSTAMPS
         // diagnostic build only: where does a slab's time go? sums over the slabs of this tile, per wave group
-        unsigned long long ks_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long ks_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long ks_prev = __builtin_amdgcn_s_memtime();
 #define KSTAMP4(i_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ks_sum[i_] += now_ - ks_prev; ks_prev = now_; } while (0)
 #else
 #define KSTAMP4(i_) do {} while (0)
 #endif
-        for (int ks = 0; ks < KS; ++ks, ++g) {
+        // One slab. STEADY = a slab that is neither the first of its tile nor one of the stream's last two: its wait is
+        // always vmcnt(4), written without a single scalar instruction behind the MFMAs of C1. Measured with interval stamps
+        // (-DCOGS_GEMM_KSTAMPS build): whatever DECIDES at that point -- the compiler's lane-mask conversion (v_cndmask /
+        // v_cmp writing an SGPR) or a tree of s_cmp / taken s_cbranch on a pinned SGPR -- costs 180-340 cycles per slab
+        // there, against 4 cycles for nothing. Group 1, whose wait stands at the end of L1, executes the C1 wait too: by
+        // then it has at most A(g+2) outstanding, so it falls through. The other slabs take the general form, with the
+        // count chosen at the top of the slab and pinned into SGPRs (opaque s_mov).
+        auto slab = [&](auto steady_tag, const int ks) __attribute__((always_inline)) {
+            constexpr bool STEADY = decltype(steady_tag)::value;
             const char* ua = smem + ra * UNIT4;
             const char* uw = smem + rw * UNIT4;
+            int wm_l1 = 4, wm_c1 = 4;
+            if constexpr (!STEADY) {
+                const int wmode = wait_mode(g, ks == 0 && g > 0);
+                asm volatile("s_mov_b32 %0, %1" : "=s"(wm_l1) : "s"(__builtin_amdgcn_readfirstlane(grp == 1 ? wmode : 4)));
+                asm volatile("s_mov_b32 %0, %1" : "=s"(wm_c1) : "s"(__builtin_amdgcn_readfirstlane(grp == 0 ? wmode : 4)));
+            }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int ao = a_off ^ (half << 6), wo = w_off ^ (half << 6);   // k-chunk index ^ 4
@@ -781,16 +796,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
                 // W(g+1) -> position of A(g-1), A(g+2) -> position of W(g-1): both groups drained their reads of slab
                 // g-1 (lgkmcnt(0)) before the barrier that opened this slab's first interval (WAR safe)
                 if (half == 1) issue_a();
-                else if (!pre_issued) issue_w();
+                else if (STEADY || !pre_issued) issue_w();
                 if (half == 0) pre_issued = false;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(afr[0]), "+v"(afr[1]), "+v"(afr[2]), "+v"(afr[3]), "+v"(wfr[0]), "+v"(wfr[1]),
                              "+v"(wfr[2]), "+v"(wfr[3]));
                 asm volatile("" : "+v"(afr2[0]), "+v"(afr2[1]), "+v"(afr2[2]), "+v"(afr2[3]));
-                if (half == 1 && grp == 1) wait_next_slab(g, ks == 0 && g > 0);
-                KSTAMP4(half * 4 + 0);
+                if (half == 1) {
+                    if constexpr (STEADY) { if (is_g1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                    else wait_next_slab(wm_l1);
+                }
+                KSTAMP4(half * 6 + 0);
                 __builtin_amdgcn_s_barrier();
-                KSTAMP4(half * 4 + 1);
+                KSTAMP4(half * 6 + 1);
                 // ---- C segment: 32 MFMAs ----
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -799,6 +817,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
                     for (int ni = 0; ni < 4; ++ni)
                         acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr[mi]), acc[0][mi][ni], 0, 0, 0);
+#ifdef COGS_GEMM_KSTAMPS
+                __builtin_amdgcn_sched_barrier(0);
+                KSTAMP4(half * 6 + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -806,21 +829,32 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
                         acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr2[mi]), acc[1][mi][ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (half == 1 && grp == 0) wait_next_slab(g, ks == 0 && g > 0);
-                KSTAMP4(half * 4 + 2);
+                KSTAMP4(half * 6 + 3);
+                if (half == 1) {
+                    if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else wait_next_slab(wm_c1);
+                }
+                KSTAMP4(half * 6 + 4);
                 __builtin_amdgcn_s_barrier();
-                KSTAMP4(half * 4 + 3);
+                KSTAMP4(half * 6 + 5);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(0);
                 asm volatile("" ::: "memory");
             }
             ra = ra + 2 >= RING4 ? ra + 2 - RING4 : ra + 2;
             rw = rw + 2 >= RING4 ? rw + 2 - RING4 : rw + 2;
-        }
+        };
+        // (three copies of the slab in a row rather than one loop with a branch around two: the diamond made the register
+        // allocator spill ~190 registers)
+        int ks = 0;
+        slab(std::false_type{}, ks);
+        ++ks; ++g;
+        for (; ks < KS && g < total - 2; ++ks, ++g) slab(std::true_type{}, ks);
+        for (; ks < KS; ++ks, ++g) slab(std::false_type{}, ks);
 #ifdef COGS_GEMM_KSTAMPS
         if (p.trace && blockIdx.x == 0 && wc == 0 && lane == 0 && t == (int)blockIdx.x) {   // first tile of workgroup 0
-            unsigned long long* o = p.trace + 192 + grp * 8;
-            for (int i = 0; i < 8; ++i) o[i] = ks_sum[i];
+            unsigned long long* o = p.trace + 192 + grp * 12;
+            for (int i = 0; i < 12; ++i) o[i] = ks_sum[i];
         }
 #endif
         // W of the next tile's second slab goes out in front of the epilogue (into the position of this tile's last A
@@ -832,7 +866,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
 #ifdef COGS_EPI_CONSERVATIVE
         epi_ops = 0; (void)ops;
 #else
-        epi_ops = ops > 0 ? ops : 0;
+        epi_ops = __builtin_amdgcn_readfirstlane(ops > 0 ? ops : 0);
 #endif
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
@@ -867,6 +901,13 @@ void launch_big(hipStream_t st, const GemmArgs& p, int grid) {
     ++g_gemm_launches;
     hipLaunchKernelGGL((gemm_tn_256x128_kernel<T, EPI>), dim3(wgs), dim3(512), lds, st, p);
 }
+// COGS_GEMM_PP64=0 keeps the 32-wide K-tile kernel (A/B runs); default: the whole-line kernel wherever it exists (every
+// epilogue but the rotary LUT one, for which it has no LDS left -- cogs_k_gemm then takes the rotary factors from global
+// memory instead: measured 1 % faster end to end than the LUT epilogue on the old body)
+bool pp64_enabled() {
+    static const bool on = !getenv("COGS_GEMM_PP64") || atoi(getenv("COGS_GEMM_PP64")) != 0;
+    return on;
+}
 template <int EPI>
 void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
     const size_t lds = RING3 * SLOT3 + ((EPI & EPI_ROPE_LUT) ? 28 * 1024 : 0);   // ring (+ rotary LUT, <= 28 KiB)
@@ -875,11 +916,11 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
     static const bool env_trace = getenv("COGS_GEMM_TRACE") != nullptr;
     if (env_trace) {
         static unsigned long long* dbuf = nullptr;
-        if (!dbuf) (void)hipMalloc(&dbuf, 208 * 8);
-        (void)hipMemsetAsync(dbuf, 0, 208 * 8, st);
+        if (!dbuf) (void)hipMalloc(&dbuf, 224 * 8);
+        (void)hipMemsetAsync(dbuf, 0, 224 * 8, st);
         GemmArgs q = p;
         q.trace = dbuf;
-        static const bool env_pp64t = getenv("COGS_GEMM_PP64") && atoi(getenv("COGS_GEMM_PP64")) != 0;
+        const bool env_pp64t = pp64_enabled();
         bool done64 = false;
         if constexpr ((EPI & EPI_ROPE_LUT) == 0) {
             if (env_pp64t) {
@@ -891,7 +932,7 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         }
         if (!done64)
         hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, q);
-        unsigned long long h[208];
+        unsigned long long h[224];
         (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
         for (int g = 0; g < 2; ++g) {
@@ -905,10 +946,12 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         for (int g = 0; g < 2; ++g) {
             const unsigned long long* o = h + 192 + g * 8;
             const double kt_n = p.K / 32.0;
-            if (env_pp64t && (EPI & EPI_ROPE_LUT) == 0)
-                fprintf(stderr, "[gemm kstamps] group %d per 64-wide slab: L0 %.0f wait %.0f C0 %.0f wait %.0f | L1 %.0f wait %.0f C1 %.0f wait %.0f\n",
-                        g, o[0] / (kt_n / 2), o[1] / (kt_n / 2), o[2] / (kt_n / 2), o[3] / (kt_n / 2), o[4] / (kt_n / 2),
-                        o[5] / (kt_n / 2), o[6] / (kt_n / 2), o[7] / (kt_n / 2));
+            if (env_pp64t && (EPI & EPI_ROPE_LUT) == 0) {
+                const unsigned long long* q = h + 192 + g * 12;
+                const double sl = kt_n / 2;
+                fprintf(stderr, "[gemm kstamps] group %d per 64-wide slab: L0 %.0f wait %.0f C0 %.0f+%.0f vm %.0f wait %.0f | L1 %.0f wait %.0f C1 %.0f+%.0f vm %.0f wait %.0f\n",
+                        g, q[0] / sl, q[1] / sl, q[2] / sl, q[3] / sl, q[4] / sl, q[5] / sl, q[6] / sl, q[7] / sl, q[8] / sl, q[9] / sl, q[10] / sl, q[11] / sl);
+            }
             else
             fprintf(stderr, "[gemm kstamps] group %d per K-tile: L %.0f wait %.0f C %.0f wait %.0f\n",
                     g, o[0] / kt_n, o[1] / kt_n, o[2] / kt_n, o[3] / kt_n);
@@ -917,7 +960,7 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         return;
     }
     ++g_gemm_launches;
-    static const bool env_pp64 = getenv("COGS_GEMM_PP64") && atoi(getenv("COGS_GEMM_PP64")) != 0;   // A/B runs
+    const bool env_pp64 = pp64_enabled();
     if constexpr ((EPI & EPI_ROPE_LUT) == 0) {
         if (env_pp64) {
             static std::atomic<uint64_t> attr_done64{0};
@@ -1015,7 +1058,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         p.group_m = env_gm > 0 ? env_gm : ((p.nbn <= 6 && g.K >= 2048) ? 2 : GROUP_M);
         int pp_mask = cogs_epi_mask(g);
         p.rope_lut = nullptr; p.rope_lut_bytes = 0;
-        if ((pp_mask & ~EPI_LNFOLD) == (EPI_BIAS | EPI_ROPE) && g.rope_lut && g.rope_rowpos && !g.rope_sin && !env_nolut) {
+        if ((pp_mask & ~EPI_LNFOLD) == (EPI_BIAS | EPI_ROPE) && g.rope_lut && g.rope_rowpos && !g.rope_sin && !env_nolut && !pp64_enabled()) {
             const int lut_bytes = g.rope_maxpos * (g.head_dim / 4) * 8;
             if (lut_bytes > 0 && lut_bytes <= 28 * 1024 && g.rope_maxpos < 65536) {
                 pp_mask |= EPI_ROPE_LUT;
