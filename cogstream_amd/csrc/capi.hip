@@ -496,12 +496,14 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
         if (ok) {
             const size_t pes = pix_dtype == COGS_DT_BF16 ? 2 : 4;
             if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0) != hipSuccess) return COGS_E_HIP;
+            cogs_k_gemm_co_streams(2);
             const cogs_status ra = vit_encode_range(h, st, pixel_values, pix_dtype, ga.data(), ma.data(), (int)ma.size(), attn_mode,
                                                     out_tokens, ws, need_a);
             const cogs_status rb = vit_encode_range(h, h->aux_stream, (const char*)pixel_values + (size_t)rows_a * w.patch_dim * pes,
                                                     pix_dtype, gb.data(), mb.data(), (int)mb.size(), attn_mode,
                                                     (char*)out_tokens + (size_t)toks_a * w.hidden * esize(w.dtype),
                                                     (char*)ws + need_a, need_b);
+            cogs_k_gemm_co_streams(1);
             // join unconditionally: the caller's stream must not run ahead of anything queued on the second one
             if (hipEventRecord(h->ev_join, h->aux_stream) != hipSuccess || hipStreamWaitEvent(st, h->ev_join, 0) != hipSuccess) return COGS_E_HIP;
             return ra != COGS_OK ? ra : rb;

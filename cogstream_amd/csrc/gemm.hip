@@ -877,6 +877,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
 // kernel launches issued by cogs_k_gemm on this thread (a round-aligned split is two): lets the profiler bracket
 // report per-KERNEL averages that can be compared with rocprofv3's kernel stats
 static thread_local long g_gemm_launches = 0;
+// how many streams the caller is feeding with GEMMs of this size at the same time (cogs_vit_encode's two-stream mode: 2).
+// Only the few-tile choice below reads it: with a second stream filling the CUs a launch leaves idle, a partly filled
+// round costs its share of the chip, not a whole round.
+static thread_local int g_co_streams = 1;
+void cogs_k_gemm_co_streams(int streams) { g_co_streams = streams < 1 ? 1 : streams; }
 long cogs_k_gemm_launch_count() { return g_gemm_launches; }
 
 int cogs_k_gemv(hipStream_t st, const CogsGemm& g);
@@ -1077,33 +1082,46 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         int mb_main = -1;      // >= 0: row blocks that stay in this kernel (0 = none: the whole GEMM goes to the ring kernel)
         // (calibrated on K = 1152 .. 4352, the ViT shapes; longer K -- the Qwen2 prompt pass at M = 2048 -- keeps the
         // plain ping-pong launch)
+        static const int env_co = getenv("COGS_GEMM_COSTREAMS") ? atoi(getenv("COGS_GEMM_COSTREAMS")) : 0;   // A/B runs
+        const int S = env_co > 0 ? env_co : g_co_streams;
         if (!env_nosplit && !env_nostore && nb <= 2 * PERSISTENT_WGS && g.K <= 4352) {
             // Few tiles (one rank's share of a frame-sharded clip: M = 6 400 is 125 tiles for N = 1152 and 350 = 1.37
             // rounds for QKV): the time is rounds x one tile, so the choice is by rounds. Calibrated on the four ViT
-            // shapes at M = 3 200 .. 14 784 (tools/cal_tiles.sh, rocprofv3): a round of 256x128 ring tiles takes 0.64-0.68 of a
-            // round of ping-pong tiles of the same K; a second launch costs about 0.08 of one.
+            // shapes at M = 3 200 .. 14 784 (tools/cal_tiles.sh, rocprofv3; round 4 with the whole-line kernel,
+            // tools/experiments/cring_sweep.sh): a round of 256x128 ring tiles takes 0.72 of a round of ping-pong tiles of
+            // the same K; a second launch costs about 0.08 of one. With a second stream running the other half of the clip
+            // (S = 2) the CUs a launch leaves idle are not lost, so a launch costs max(1, its share of the chip) and is never
+            // split: measured at 3 200 / 3 696 / 6 400 / 14 784 rows per stream, the ring kernel wins the first two (65 and
+            // 75 ping-pong tiles: -2 %, -7 % of the step), the ping-pong kernel the third (125 tiles: -12 %) and the unsplit
+            // launch the last (-4 %).
             const int rbm = (g.M + BM2 - 1) / BM2, rbn = (g.N + BN - 1) / BN;
-            auto ring_rounds = [&](int row_blocks) { return (row_blocks * rbn + PERSISTENT_WGS - 1) / PERSISTENT_WGS; };
-            const float c_ring = 0.66f, c_launch = 0.08f;
-            const float cost_pp = (float)((nb + PERSISTENT_WGS - 1) / PERSISTENT_WGS);
-            const float cost_ring = c_ring * ring_rounds(rbm);
+            auto launch_cost = [&](int tiles) {
+                return S == 1 ? (float)((tiles + PERSISTENT_WGS - 1) / PERSISTENT_WGS)
+                              : fmaxf(1.f, (float)S * (float)tiles / (float)PERSISTENT_WGS);
+            };
+            static const float c_ring = getenv("COGS_GEMM_CRING") ? (float)atof(getenv("COGS_GEMM_CRING")) : 0.72f;   // env: calibration sweeps
+            const float c_launch = 0.08f;
+            const float cost_pp = launch_cost(nb);
+            const float cost_ring = c_ring * launch_cost(rbm * rbn);
             float best = cost_pp;
             if (cost_ring < best) { best = cost_ring; mb_main = 0; }
-            if (rounds == 1 && rem > 0) {
+            if (S == 1 && rounds == 1 && rem > 0) {
                 const int mb = PERSISTENT_WGS / p.nbn;                 // whole row blocks inside the first round
                 const int rows_rem = g.M - mb * BM3;
                 if (mb > 0 && rows_rem >= 512) {     // the remainder must reach the 256x128 ring kernel the cost model prices
-                    const float cost_split = 1.f + c_ring * ring_rounds((rows_rem + BM2 - 1) / BM2) + c_launch;
+                    const float cost_split = 1.f + c_ring * launch_cost(((rows_rem + BM2 - 1) / BM2) * rbn) + c_launch;
                     if (cost_split < best) { best = cost_split; mb_main = mb; }
                 }
             }
-        } else if (!env_nosplit && !env_nostore && g.K >= 2048 && rounds >= 2 && rem > 0 && rem * 100 < PERSISTENT_WGS * 45) {
+        } else if (S == 1 && !env_nosplit && !env_nostore && g.K >= 2048 && rounds >= 2 && rem > 0 && rem * 100 < PERSISTENT_WGS * 45) {
             // (many tiles: pays when a tile is long against a second launch and the last round is less than ~45 % full:
             // measured with the two-segment K loop at K = 1152: -2 %; K = 3584, last round 34 % full: +2 %; K = 18944,
             // 34 %: +6 %; K = 4352, 51 % full (ViT fc2): -2 %, so it no longer splits)
             const int mb = rounds * PERSISTENT_WGS / p.nbn;          // whole row blocks within the full rounds
             if (mb > 0 && g.M - mb * BM3 >= 512) mb_main = mb;
         }
+        static const bool env_choice = getenv("COGS_GEMM_CHOICE") != nullptr;      // diagnostics: which body each shape gets
+        if (env_choice) fprintf(stderr, "[gemm choice] M=%d N=%d K=%d: %d ping-pong tiles (%d rounds + %d), mb_main %d\n", g.M, g.N, g.K, nb, rounds, rem, mb_main);
         if (mb_main >= 0) {
             const int rows_main = mb_main * BM3;
             CogsGemm b = g;

@@ -45,6 +45,7 @@ struct CogsGemm {
                                              //   (include/cogs.h, cogs_gemm_desc.ln_ab, has the contract)
 };
 int cogs_k_gemm(hipStream_t st, const CogsGemm& g);
+void cogs_k_gemm_co_streams(int streams);   // hint for the few-tile choice: streams fed with GEMMs of this size at once (thread-local)
 // (a, b) = (rstd, -rstd * mean) per row from the EPI_ROWSTAT partials [rows][tiles][2]: ab [rows][2]
 int cogs_k_ln_finalize(hipStream_t st, const float* stat_part, int rows, int tiles, int H, float eps, float* ab);
 // (a, b) = (rstd, -rstd * mean) per row from the EPI_ROWSTAT partials: ab [rows][2]
