@@ -46,6 +46,7 @@ struct GemmArgs {
     int nbm, nbn;
     const float* rope_lut; int rope_lut_bytes;   // EPI_ROPE_LUT: global LUT copied to LDS behind the ring at kernel start
     int group_m;                 // ping-pong kernel: row blocks per group of the tile walk (L2 footprint of an XCD)
+    int epi_serial;              // whole-line kernel, A/B runs (COGS_GEMM_EPISERIAL=1): both groups' epilogues behind the tile's last barrier
     unsigned long long* trace;   // diagnostics (COGS_GEMM_TRACE): per-tile s_memtime stamps of WG 0, waves 0 and 4
     EpiArgs epi;
 };
@@ -773,8 +774,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
         // there, against 4 cycles for nothing. Group 1, whose wait stands at the end of L1, executes the C1 wait too: by
         // then it has at most A(g+2) outstanding, so it falls through. The other slabs take the general form, with the
         // count chosen at the top of the slab and pinned into SGPRs (opaque s_mov).
-        auto slab = [&](auto steady_tag, const int ks) __attribute__((always_inline)) {
+        auto slab = [&](auto steady_tag, auto last_tag, const int ks) __attribute__((always_inline)) {
             constexpr bool STEADY = decltype(steady_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;      // last slab of the tile: its closing barrier belongs to the tile end below
             const char* ua = smem + ra * UNIT4;
             const char* uw = smem + rw * UNIT4;
             int wm_l1 = 4, wm_c1 = 4;
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
                     else wait_next_slab(wm_c1);
                 }
                 KSTAMP4(half * 6 + 4);
-                __builtin_amdgcn_s_barrier();
+                if (!(LAST && half == 1)) __builtin_amdgcn_s_barrier();
                 KSTAMP4(half * 6 + 5);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(0);
@@ -844,25 +846,31 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
             ra = ra + 2 >= RING4 ? ra + 2 - RING4 : ra + 2;
             rw = rw + 2 >= RING4 ? rw + 2 - RING4 : rw + 2;
         };
-        // (three copies of the slab in a row rather than one loop with a branch around two: the diamond made the register
-        // allocator spill ~190 registers)
+        // (four copies of the slab in a row -- first, steady, the stream's tail, last of the tile -- rather than one loop
+        // with branches around them: a diamond made the register allocator spill ~190 registers; KS >= 2 by the launcher)
         int ks = 0;
-        slab(std::false_type{}, ks);
+        slab(std::false_type{}, std::false_type{}, ks);
         ++ks; ++g;
-        for (; ks < KS && g < total - 2; ++ks, ++g) slab(std::true_type{}, ks);
-        for (; ks < KS; ++ks, ++g) slab(std::false_type{}, ks);
+        for (; ks < KS - 1 && g < total - 2; ++ks, ++g) slab(std::true_type{}, std::false_type{}, ks);
+        for (; ks < KS - 1; ++ks, ++g) slab(std::false_type{}, std::false_type{}, ks);
+        slab(std::false_type{}, std::true_type{}, ks);
+        ++ks; ++g;
 #ifdef COGS_GEMM_KSTAMPS
         if (p.trace && blockIdx.x == 0 && wc == 0 && lane == 0 && t == (int)blockIdx.x) {   // first tile of workgroup 0
             unsigned long long* o = p.trace + 192 + grp * 12;
             for (int i = 0; i < 12; ++i) o[i] = ks_sum[i];
         }
 #endif
-        // W of the next tile's second slab goes out in front of the epilogue (into the position of this tile's last A
-        // unit: both groups drained their reads of it before the barrier above). The epilogue runs inside this group's
-        // next L interval, i.e. beside the other group's C.
+        // Tile end. The barrier that closes the last slab stands BEFORE group 0's epilogue and BEHIND group 1's, so the
+        // two epilogues share one interval (group 0: epilogue + first load segment of the next tile; group 1: its last
+        // MFMA segment + epilogue) instead of taking one each while the other group waits at a barrier.
+        // W of the next tile's second slab goes out in front of the epilogue, into the position of this tile's last A
+        // unit: a wave stages rows 32w..32w+31 of it, rows that only its own group read (before this point).
+        if (grp == 0 || p.epi_serial) __builtin_amdgcn_s_barrier();
         issue_w();
         pre_issued = true;
         const int ops = epilogue_wave_pair<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0], acc[1]);
+        if (grp == 1 && !p.epi_serial) __builtin_amdgcn_s_barrier();
 #ifdef COGS_EPI_CONSERVATIVE
         epi_ops = 0; (void)ops;
 #else
@@ -928,7 +936,7 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         const bool env_pp64t = pp64_enabled();
         bool done64 = false;
         if constexpr ((EPI & EPI_ROPE_LUT) == 0) {
-            if (env_pp64t) {
+            if (env_pp64t && p.K >= 128) {
                 static std::atomic<uint64_t> attr_done64t{0};
                 cogs_ensure_dyn_lds((const void*)gemm_tn_pp64_kernel<EPI>, RING4 * UNIT4, attr_done64t);
                 hipLaunchKernelGGL((gemm_tn_pp64_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), RING4 * UNIT4, st, q);
@@ -967,7 +975,7 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
     ++g_gemm_launches;
     const bool env_pp64 = pp64_enabled();
     if constexpr ((EPI & EPI_ROPE_LUT) == 0) {
-        if (env_pp64) {
+        if (env_pp64 && p.K >= 128) {
             static std::atomic<uint64_t> attr_done64{0};
             cogs_ensure_dyn_lds((const void*)gemm_tn_pp64_kernel<EPI>, RING4 * UNIT4, attr_done64);
             hipLaunchKernelGGL((gemm_tn_pp64_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), RING4 * UNIT4, st, p);
@@ -1040,6 +1048,8 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     if (g.rms_gamma) return COGS_E_UNSUPPORTED;   // fused RMSNorm exists for the single-token GEMV only
     GemmArgs p;
     p.trace = nullptr; p.rope_lut = nullptr; p.rope_lut_bytes = 0; p.group_m = GROUP_M;
+    static const int env_epi_serial = getenv("COGS_GEMM_EPISERIAL") ? atoi(getenv("COGS_GEMM_EPISERIAL")) : 0;
+    p.epi_serial = env_epi_serial;
     const int rc = cogs_fill_epi(g, &p.epi);
     if (rc != COGS_OK) return rc;
     p.A = (const char*)g.A; p.lda = g.lda * es;
