@@ -542,7 +542,7 @@ def main() -> None:
                 traffic_src = f"committed PMC profile profiles/{name} (separate rocprofv3 --pmc passes of this command), not this run"
                 break
         out["roofline"] = {"bound": "mfma",
-                           "kernel": "bf16 MFMA GEMM (gemm_tn_pp_kernel<*> + gemm_tn_256x128_kernel<*>: every encoder+"
+                           "kernel": "bf16 MFMA GEMM (gemm_tn_pp64_kernel<*> + gemm_tn_256x128_kernel<*>: every encoder+"
                                      "projector GEMM kernel of one step; a round-aligned split counts as two launches)",
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,

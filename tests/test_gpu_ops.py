@@ -558,6 +558,60 @@ def test_pair_epilogue_and_relaxed_vmcnt_equal_the_generic_build_bit_for_bit(dev
             assert torch.equal(a, b), (name, rep, float((a.float() - b.float()).abs().max()))
 
 
+def test_whole_line_gemm_equals_the_k_tile_gemm_bit_for_bit(dev, tmp_path, monkeypatch):
+    """gemm_tn_pp64_kernel (round 4: 64-wide slabs of whole 128-byte lines in a five-unit ring, three kinds of slab, the
+    two wave groups' epilogues in one interval) must produce the bits of gemm_tn_pp_kernel (32-wide K-tiles): same tile,
+    same MFMA order, same epilogues. The second kernel is reached through a private copy of the library that reads
+    COGS_GEMM_PP64=0 when it initialises. Shapes: the cfg2 ViT GEMMs at a quarter of the clip (several rounds of the
+    persistent grid, ragged last row block), a frame-sharded share (few tiles), the Qwen2 gate/up and down projections
+    at 2 100 rows (SwiGLU epilogue; K = 18 944: 296 slabs per tile)."""
+    import ctypes as C
+    import shutil
+    from cogstream_amd import _lib as L2
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(11)
+    rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).bfloat16()
+    ops.gemm(rnd(1024, 128), rnd(256, 128))                       # the shipped library has read its environment
+    torch.cuda.synchronize()
+    private = tmp_path / "libcogs_hip_ktile.so"
+    shutil.copy(L2.LIB_PATH, private)
+    monkeypatch.setenv("COGS_GEMM_PP64", "0")
+    alt = C.CDLL(str(private))
+    ops.gemm(rnd(1024, 128), rnd(256, 128), lib=alt)              # ... and the private copy its own
+    torch.cuda.synchronize()
+    monkeypatch.delenv("COGS_GEMM_PP64")
+    hd, H, I = 72, 1152, 4352
+    for M in (59136 // 4 + 40, 6400):
+        x, big = rnd(M, H), rnd(M, I)
+        nf = hd // 4
+        hpos = torch.randint(0, 22, (M,), generator=g, device=dev)
+        wpos = torch.randint(0, 42, (M,), generator=g, device=dev)
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(nf, dtype=torch.float32, device=dev) / nf))
+        ang = torch.cat([hpos[:, None].float() * inv_freq, wpos[:, None].float() * inv_freq], 1)
+        table = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+        cases = [
+            ("qkv+rope table", dict(a=x, w=rnd(3 * H, H), bias=rnd(3 * H), rope_cos=table, rope_cols=2 * H, head_dim=hd)),
+            ("out-proj+res", dict(a=x, w=rnd(H, H), bias=rnd(H), residual=rnd(M, H))),
+            ("fc1+gelu", dict(a=x, w=rnd(I, H), bias=rnd(I), act=L2.ACT_GELU_TANH)),
+            ("fc2+res", dict(a=big, w=rnd(H, I), bias=rnd(H), residual=rnd(M, H))),
+            ("plain", dict(a=x, w=rnd(3584, H))),
+            ("K = 128 (two slabs)", dict(a=rnd(M, 128), w=rnd(H, 128))),
+        ]
+        for name, kw in cases:
+            for rep in range(2):
+                a = ops.gemm(**kw)
+                b = ops.gemm(**kw, lib=alt)
+                torch.cuda.synchronize()
+                assert torch.equal(a, b), (M, name, rep, float((a.float() - b.float()).abs().max()))
+    xq, inter = rnd(2100, 3584), rnd(2100, 18944)
+    for name, kw in (("gate/up swiglu", dict(a=xq, w=rnd(2 * 18944, 3584), act=L2.ACT_SWIGLU)),
+                     ("down+res", dict(a=inter, w=rnd(3584, 18944), residual=rnd(2100, 3584)))):
+        a = ops.gemm(**kw)
+        b = ops.gemm(**kw, lib=alt)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+
+
 @pytest.mark.parametrize("M", [300, 1300, 4096])
 def test_gemm_row_stats_and_ln_fold(dev, M):
     """LayerNorm fused around the GEMMs: (1) a residual-stream GEMM (N = hidden) also writes per-row partial sums,
