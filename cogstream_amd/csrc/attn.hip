@@ -39,6 +39,8 @@ struct AttnArgs {
     int q_pos0;                     // causal: key j visible to query i iff j <= i + q_pos0
     int causal;
     int heavy_first;                // causal, one sequence: query tiles in descending order
+    int prio_mode;                  // prompt kernel (COGS_ATTN_PRIO): 1 = s_setprio 1 around the MFMA blocks, 2 (default) = around the softmax: the two
+                                    // waves of a SIMD, which belong to different workgroups, fall out of step, one's MFMAs beside the other's VALU
     int nsplit;                     // >1: keys split over blocks, partials go to part_o/part_ml
     int gqa_pack;                   // decode: the q-heads of one kv head are the 16 query columns
     int q_prescaled;                // Q already carries scale*log2(e): use the PRE kernels
@@ -610,6 +612,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
         const int kbase = ks + kt * 64;
         const bool second_half = !MASKED || kbase + 32 < kend;
         f32x4 sacc[4][NQ];
+        if (p.prio_mode == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int ut = 0; ut < 4; ++ut) {
             if (MASKED && ut >= 2 && !second_half) {
@@ -631,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
                 }
             }
         }
+        if (p.prio_mode == 1) __builtin_amdgcn_s_setprio(0); else if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(1);
         bf16x8 pf[2][NQ];
         float post_alpha[NQ];
 #pragma unroll
@@ -692,6 +696,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
                 pf[u][qi] = __builtin_bit_cast(bf16x8, w);
             }
         }
+        if (p.prio_mode == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
 #pragma unroll
@@ -904,6 +909,8 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
     p.nsplit = 1; p.gqa_pack = 0; p.q_prescaled = 0; p.part_o = nullptr; p.part_ml = nullptr;
     static const bool env_light_first = getenv("COGS_ATTN_LIGHT_FIRST") && atoi(getenv("COGS_ATTN_LIGHT_FIRST")) == 1;   // A/B runs only
     p.heavy_first = (a.causal && !a.cu_seqlens && a.q_len > 128 && !env_light_first) ? 1 : 0;
+    static const int env_prio = getenv("COGS_ATTN_PRIO") ? atoi(getenv("COGS_ATTN_PRIO")) : 2;   // in-run A/B at 15 395 tokens: 0 / 1 / 2 = 1.90-1.91 / 1.88-1.89 / 1.83 ms per layer
+    p.prio_mode = env_prio;
     // the encoder's production shape (per-frame segments, hd 72, pre-scaled Q, no masks) has its own kernel
     static const bool env_old_vit = getenv("COGS_ATTN_VIT") && atoi(getenv("COGS_ATTN_VIT")) == 0;   // A/B runs only
     if (a.dtype == COGS_DT_BF16 && !a.force_rowwise && a.head_dim == 72 && a.q_prescaled && a.cu_seqlens && !a.row_lo &&
