@@ -74,8 +74,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hq: int, hkv
               scale: Optional[float] = None, cu_seqlens: Optional[torch.Tensor] = None, max_seqlen: int = 0,
               row_lo: Optional[torch.Tensor] = None, row_hi: Optional[torch.Tensor] = None, bias: float = 0.0,
               causal: bool = False, q_pos0: int = 0, force_rowwise: bool = False, nsplit: int = 1,
-              out: Optional[torch.Tensor] = None, q_prescaled: bool = False) -> torch.Tensor:
-    """token-major attention: q [Lq, hq*hd] (may be a column view of a fused buffer), k/v [Lk, hkv*hd]"""
+              out: Optional[torch.Tensor] = None, q_prescaled: bool = False, lib=None) -> torch.Tensor:
+    """token-major attention: q [Lq, hq*hd] (may be a column view of a fused buffer), k/v [Lk, hkv*hd]. lib: another build of
+    the library (tests: A/B identity)"""
     _need_cuda(q, k, v)
     Lq, Lk = q.shape[0], k.shape[0]
     if out is None:
@@ -100,7 +101,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hq: int, hkv
         d.nsplit, d.ws, d.ws_bytes = nsplit, ptr(ws), ws.numel() * 4
     else:
         d.nsplit = 1
-    check(L.lib.cogs_attention(current_stream(), C.byref(d)), "cogs_attention")
+    fn = L.lib.cogs_attention
+    if lib is not None:
+        fn = lib.cogs_attention
+        fn.restype, fn.argtypes = L.SIGNATURES["cogs_attention"]
+    check(fn(current_stream(), C.byref(d)), "cogs_attention")
     return out
 
 

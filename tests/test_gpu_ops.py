@@ -612,6 +612,35 @@ def test_whole_line_gemm_equals_the_k_tile_gemm_bit_for_bit(dev, tmp_path, monke
         assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
 
 
+def test_ping_pong_prompt_attention_equals_the_shipped_kernel_bit_for_bit(dev, tmp_path, monkeypatch):
+    """attn_prefill_pp_kernel (round 4, off by default: COGS_ATTN_PREFILL_PP=1) runs the arithmetic of
+    attn_prefill_dma_kernel in a different schedule (256 query rows per workgroup, two wave groups half a tile apart,
+    the PV product of a tile one phase late, no skipped MFMAs on masked tiles): the outputs must be the same bits.
+    Whole prompt, ragged lengths (one group of the last block idle / partly filled), prefix-KV continuation (q_pos0)."""
+    import ctypes as C
+    import shutil
+    from cogstream_amd import _lib as L2
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(3)
+    hq, hkv, hd = 28, 4, 128
+    mk = lambda n, h: (torch.randn(n, h * hd, generator=g, device=dev) * 0.5).bfloat16()
+    ops.attention(mk(300, hq), mk(300, hkv), mk(300, hkv), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True)
+    torch.cuda.synchronize()                                      # the shipped library has read its environment
+    private = tmp_path / "libcogs_hip_pp.so"
+    shutil.copy(L2.LIB_PATH, private)
+    monkeypatch.setenv("COGS_ATTN_PREFILL_PP", "1")
+    alt = C.CDLL(str(private))
+    ops.attention(mk(300, hq), mk(300, hkv), mk(300, hkv), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True, lib=alt)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("COGS_ATTN_PREFILL_PP")
+    for S, pos0 in ((4096, 0), (2100, 0), (2433, 0), (300, 0), (1000, 1500)):
+        q, kk, v = mk(S, hq), mk(S + pos0, hkv), mk(S + pos0, hkv)
+        a = ops.attention(q, kk, v, hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True, q_pos0=pos0)
+        b = ops.attention(q, kk, v, hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True, q_pos0=pos0, lib=alt)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (S, pos0, float((a.float() - b.float()).abs().max()))
+
+
 @pytest.mark.parametrize("M", [300, 1300, 4096])
 def test_gemm_row_stats_and_ln_fold(dev, M):
     """LayerNorm fused around the GEMMs: (1) a residual-stream GEMM (N = hidden) also writes per-row partial sums,
