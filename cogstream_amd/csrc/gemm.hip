@@ -789,11 +789,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
             for (int half = 0; half < 2; ++half) {
                 const int ao = a_off ^ (half << 6), wo = w_off ^ (half << 6);   // k-chunk index ^ 4
                 // ---- L segment: 12 fragment reads and this wave's 4 pieces of W(g+1) (first half) / A(g+2) (second) ----
-#ifdef COGS_PP64_PIECES_FIRST     // experiment: the pieces in front of the reads (longer landing budget, later reads)
-                if (half == 1) issue_a();
-                else if (STEADY || !pre_issued) issue_w();
-                if (half == 0) pre_issued = false;
-#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wfr[i] = *reinterpret_cast<const u32x4*>(uw + wo + i * 16 * ROW4);
 #pragma unroll
@@ -802,11 +797,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
                 for (int i = 0; i < 4; ++i) afr2[i] = *reinterpret_cast<const u32x4*>(ua + ao + 64 * ROW4 + i * 16 * ROW4);
                 // W(g+1) -> position of A(g-1), A(g+2) -> position of W(g-1): both groups drained their reads of slab
                 // g-1 (lgkmcnt(0)) before the barrier that opened this slab's first interval (WAR safe)
-#ifndef COGS_PP64_PIECES_FIRST
+                // (measured and dropped, in-run A/B on the encoder step: the pieces in FRONT of the reads -0.8 %; no s_setprio
+                // around the MFMA segment +-0; the upper A fragments of a slab's second half requested from inside the first
+                // half's MFMA segment, behind their last use, -0.3 %; the pieces between the MFMAs: see the header)
                 if (half == 1) issue_a();
                 else if (STEADY || !pre_issued) issue_w();
                 if (half == 0) pre_issued = false;
-#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(afr[0]), "+v"(afr[1]), "+v"(afr[2]), "+v"(afr[3]), "+v"(wfr[0]), "+v"(wfr[1]),
                              "+v"(wfr[2]), "+v"(wfr[3]));
@@ -819,9 +815,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
                 __builtin_amdgcn_s_barrier();
                 KSTAMP4(half * 6 + 1);
                 // ---- C segment: 32 MFMAs ----
-#ifndef COGS_PP64_NOPRIO
                 __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
