@@ -302,12 +302,7 @@ typedef struct {
     int hidden, inter_pad, layers, heads, patch_dim, patch_pad;
     float ln_eps;
     const void *patch_w, *patch_b, *post_ln_g, *post_ln_b;
-    const cogs_vit_layer* layer; /* cogs_vit_encode runs a clip of two or more frames as two halves on two streams (the caller's and one the handle owns;
- * frames are independent under per-frame attention, the tokens are bit-identical to a one-stream encode): the second
- * half's kernels fill the partly empty last rounds of the first half's persistent GEMM launches. streams = 1 keeps
- * everything on the caller's stream, 2 (the default) allows the split. */
-cogs_status cogs_vit_set_streams(cogs_handle h, int streams);
-/* host array [layers], copied by cogs_vit_load */
+    const cogs_vit_layer* layer; /* host array [layers], copied by cogs_vit_load */
 } cogs_vit_weights;
 cogs_status cogs_vit_load(cogs_handle h, const cogs_vit_weights* w);
 cogs_status cogs_vit_workspace_bytes(cogs_handle h, int64_t n_patches, size_t* bytes);
@@ -317,6 +312,11 @@ cogs_status cogs_vit_workspace_bytes(cogs_handle h, int64_t n_patches, size_t* b
 cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
                             const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
                             void* out_tokens, void* ws, size_t ws_bytes);
+/* cogs_vit_encode runs a clip of two or more frames as two halves on two streams (the caller's and one the handle owns;
+ * frames are independent under per-frame attention, the tokens are bit-identical to a one-stream encode): the second
+ * half's kernels fill the partly empty last rounds of the first half's persistent GEMM launches. streams = 1 keeps
+ * everything on the caller's stream, 2 (the default) allows the split. */
+cogs_status cogs_vit_set_streams(cogs_handle h, int streams);
 
 /* ----------------------------------------------------------------------- multi-GPU ------ */
 

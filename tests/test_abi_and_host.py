@@ -23,6 +23,21 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.lib.cogs_version()
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/cogs.h is the boundary a C caller binds: it must compile as C99 on its own, every entry point a
+    file-scope declaration (a function declared inside a struct body is C++ only and hides the symbol from C)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "cogs.h"\nint main(void) { cogs_gemm_desc d; cogs_vit_weights w; (void)d; (void)w;\n'
+                   '  cogs_status (*f)(cogs_handle, int) = cogs_vit_set_streams; (void)f; return (int)(sizeof(cogs_kv) == 0); }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_no_cpu_fallback():
     """CPU tensors must be rejected loudly, never computed on the host"""
     if torch.cuda.is_available():
