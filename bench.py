@@ -80,12 +80,20 @@ def prompt_tokens(T: int, P: int) -> int:
 HBM_PEAK_TBPS = 8.0        # HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s is the measured copy ceiling)
 
 
-def hbm_stage(name, kernel, ref, nbytes, seconds, note):
-    """one HBM-bound stage of SURVEY.md section 8(d): algorithmic bytes / wall time of the stage vs the 8 TB/s peak"""
+def hbm_stage(name, kernel, ref, nbytes, seconds, note, cache_seconds=None):
+    """one HBM-bound stage of SURVEY.md section 8(d): algorithmic bytes / wall time of the stage vs the 8 TB/s peak.
+    `seconds` is measured on ROTATING buffers whose total exceeds the 256 MiB Infinity Cache (every call finds its
+    operands in HBM); cache_seconds, when given, is the same call repeated on ONE set of buffers (operands resident in
+    the Infinity Cache after the first call) -- reported beside it as `cache_resident`, never as the roofline figure."""
     tbps = nbytes / seconds / 1e12
-    return {"stage": name, "kernel": kernel, "reference": ref, "bound": "hbm", "algorithmic_bytes": int(nbytes),
-            "ms": round(seconds * 1e3, 4), "achieved_TBps": round(tbps, 3), "peak_TBps": HBM_PEAK_TBPS,
-            "frac": round(tbps / HBM_PEAK_TBPS, 4), "note": note}
+    rec = {"stage": name, "kernel": kernel, "reference": ref, "bound": "hbm", "algorithmic_bytes": int(nbytes),
+           "ms": round(seconds * 1e3, 4), "achieved_TBps": round(tbps, 3), "peak_TBps": HBM_PEAK_TBPS,
+           "frac": round(tbps / HBM_PEAK_TBPS, 4), "note": note}
+    if cache_seconds is not None:
+        rec["cache_resident"] = {"ms": round(cache_seconds * 1e3, 4), "achieved_TBps": round(nbytes / cache_seconds / 1e12, 3),
+                                 "note": "same call back to back on ONE set of buffers: served by the 256 MiB Infinity "
+                                         "Cache, not HBM (the round-3/4 figure)"}
+    return rec
 
 
 def stage_rooflines(c3, mm3, dev, with_cpu=True):
@@ -130,26 +138,50 @@ def stage_rooflines(c3, mm3, dev, with_cpu=True):
                      "model/kmeans_with_time.py:4-137", passes * T3 * P3 * D * es, t_km,
                      f"[{T3},{P3 * D}] bf16 features, K={K}: {st['kpp_passes']} k-means++ passes + {st['iterations']} Lloyd "
                      f"iterations x 2 passes (distances, means) over the features; wall time of the whole call (seeding in one "
-                     f"library call from host-drawn exponentials, Lloyd iterations queued four at a time; {st.get('kpp_path', '')})",
+                     f"library call from host-drawn exponentials, Lloyd iterations queued four at a time; {st.get('kpp_path', '')}). "
+                     f"The algorithm itself re-reads the SAME {T3 * P3 * D * es / 1e6:.0f} MB of features on every pass, so all "
+                     f"passes after the first are Infinity-Cache reads by construction -- not an artefact of the timing loop",
                      )]
     out[0]["min_rel_margin"], out[0]["rows_below_1e-3"] = st.get("min_rel_margin"), st.get("rows_below_1e-3")
     pix3 = c3["pix"]
     gh3, gw3 = c3["gh"], c3["gw"]
     Pm = gh3 * gw3 // 4
     minor = torch.zeros(T3, dtype=torch.uint8, device=dev)
-    _, t_pd = timed(lambda: ops.pixdiff_mask(pix3, T3, Pm, 0.1, 1, minor), 5, reps=50)
+    _, t_pd_cache = timed(lambda: ops.pixdiff_mask(pix3, T3, Pm, 0.1, 1, minor), 5, reps=50)
+    # rotating operands: 6 copies of the 60 MB pixel_values = 361 MB > the 256 MiB Infinity Cache, visited round robin
+    pix_ring = [pix3] + [pix3.clone() for _ in range(5)]
+    ring_i = [0]
+
+    def pd_rot():
+        ring_i[0] = (ring_i[0] + 1) % len(pix_ring)
+        return ops.pixdiff_mask(pix_ring[ring_i[0]], T3, Pm, 0.1, 1, minor)
+
+    _, t_pd = timed(pd_rot, 5, reps=48)
+    del pix_ring
     out.append(hbm_stage("_get_compression_mask (A12)", "pixdiff_kernel (csrc/compress.hip)",
                          "model/cogreasoner_chat.py:383-432", pix3.numel() * pix3.element_size(), t_pd,
                          f"pixel_values [{pix3.shape[0]},588] bf16 read once, uint8 mask [{T3 * Pm}] written; two launches "
-                         f"(difference + per-frame fix-up), 50 calls back to back per sample"))
+                         f"(difference + per-frame fix-up), 48 calls back to back per sample over 6 rotating copies of the "
+                         f"input (361 MB in all)", cache_seconds=t_pd_cache))
     # compaction + splice: every prompt row is one gathered row (embedding table or visual token), cogs_gather_rows
     S = mm3.shape[0] + 2048
     table = torch.randn(4096, D, device=dev, dtype=mm3.dtype)
     idx = torch.cat([torch.arange(2048, device=dev), -torch.arange(1, mm3.shape[0] + 1, device=dev)]).to(torch.int64)
-    _, t_g = timed(lambda: ops.gather_rows(table, mm3, idx), 5, reps=50)
+    _, t_g_cache = timed(lambda: ops.gather_rows(table, mm3, idx), 5, reps=50)
+    # rotating operands: 3 copies of the visual tokens (92 MB each) and 3 outputs (106 MB each) = 594 MB
+    mm_ring = [mm3] + [mm3.clone() for _ in range(2)]
+    out_ring = [torch.empty(S, D, device=dev, dtype=mm3.dtype) for _ in range(3)]
+
+    def g_rot():
+        ring_i[0] = (ring_i[0] + 1) % 3
+        return ops.gather_rows(table, mm_ring[ring_i[0]], idx, out=out_ring[ring_i[0]])
+
+    _, t_g = timed(g_rot, 5, reps=48)
+    del mm_ring, out_ring
     out.append(hbm_stage("_compress_visual_tokens + prepare_inputs_labels_for_multimodal (A13-A14)",
                          "gather_rows_kernel (csrc/compress.hip)", "model/cogreasoner_chat.py:449-476,567-572",
-                         2 * S * D * es, t_g, f"{S} prompt rows of {D} bf16 read + written once; 50 calls back to back per sample"))
+                         2 * S * D * es, t_g, f"{S} prompt rows of {D} bf16 read + written once; 48 calls back to back per sample "
+                         f"over 3 rotating (source, destination) pairs (594 MB in all)", cache_seconds=t_g_cache))
     if with_cpu:
         # the CPU restatement (oracle/, torch fp32 on this box's host cores) of the same stages on the same inputs, once each
         from oracle import compress as oc
@@ -260,6 +292,59 @@ def pipeline_once(model, processor, dframes, new_tokens, expect_prompt=None):
             "new_tokens": new_tokens, "stages_s": {k: round(v, 4) for k, v in split.items()}}
 
 
+def session_probe(model_factory, processor, dev, turns=8, frames_per_turn=8, new_tokens=32):
+    """BASELINE configs[3]: a multi-turn streaming session -- every turn appends one new 8-frame 480p segment and one
+    question to the conversation and answers it through the product API exactly as the reference's loop does
+    (evaluate/answer_generate.py:130-148 rebuilds the whole conversation each turn; infer = :60-76): historic-dialogue
+    retrieval (qa_selection, mode FCC) over the growing history, then generate. Run twice on fresh model objects:
+    caches off (the reference's behaviour: everything re-encoded and re-prefilled every turn) and on (visual-token cache
+    + prefix-KV reuse). Greedy, `new_tokens` tokens per answer, EOS ignored, prompt lengths of the
+    real tokenizer. -> per-turn latencies in seconds."""
+    import random
+    from cogstream_amd import processing
+    from cogstream_amd.answer_generate import infer
+    hist = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg4_history.json")))["turns"]
+    segs = []
+    for i in range(turns):
+        fr, ts = processing.synthetic_clip(frames_per_turn, kind="drift", clip_idx=i)
+        segs.append((torch.from_numpy(fr).to(dev), [t + frames_per_turn * i for t in ts], hist[i % len(hist)]["question"]))
+    rec = {"workload": f"BASELINE configs[3]: {turns} turns, each adds a {frames_per_turn}x480x854 'drift' segment + one question "
+                       f"({turns * frames_per_turn} frames by the last turn), FCC history retrieval + answer of {new_tokens} new "
+                       f"tokens per turn (greedy), through processor -> qa_selection -> generate",
+           "turns": turns, "frames_per_turn": frames_per_turn, "new_tokens": new_tokens}
+    for name, cached in (("caches_off", False), ("caches_on", True)):
+        model = model_factory()
+        if cached:
+            model.enable_visual_cache()
+            model.enable_prefix_cache()
+        lat = []
+        for rep in range(2):            # first pass warms allocations and code objects at every prompt size; second is timed
+            if cached and rep == 1:
+                model = model_factory()
+                model.enable_visual_cache()
+                model.enable_prefix_cache()
+            random.seed(0)
+            torch.manual_seed(0)
+            conv = [{"role": "system", "content": "You are a helpful assistant."}]
+            lat = []
+            for fr, ts, q in segs:
+                conv.append({"role": "user", "content": [{"type": "video", "video": fr, "timestamps": ts}, {"type": "text", "text": q}]})
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ans, _ = infer(conv, model, processor, max_new_tokens=new_tokens, do_sample=False, repetition_penalty=1.05,
+                               eos_token_id=[])
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t0)
+                conv.append({"role": "assistant", "content": ans})
+        rec[name] = {"per_turn_s": [round(x, 4) for x in lat], "session_s": round(sum(lat), 3)}
+        if cached:
+            rec[name]["visual_cache"] = str(model.visual_cache_stats)
+            rec[name]["prefix_rows_reused_of_seen"] = str(model.prefix_cache_stats())
+        del model
+    rec["speedup_with_caches"] = round(rec["caches_off"]["session_s"] / rec["caches_on"]["session_s"], 3)
+    return rec
+
+
 def build_model(dev, enc=None, proj=None):
     """the full-size model on `dev`, random-init (no checkpoint is reachable), behind the product classes"""
     from cogstream_amd import processing
@@ -329,6 +414,12 @@ def launch_ranks(n: int) -> int:
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
     sk.close()
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the ROCm runtime of this image shares device memory between processes either through
+    # the legacy KFD IPC handles or through dmabuf file descriptors; the host driver of the MI355X boxes supports only
+    # the dmabuf form, and with the legacy mode (the runtime's default) RCCL's intra-node transport setup -- every rank
+    # maps its peers' buffers with hipIpcGetMemHandle / hipIpcOpenMemHandle -- fails with "hipIpcGetMemHandle: invalid
+    # argument". The image exports the variable already; it is set here only so that ranks started from a scrubbed
+    # environment still get it. An explicit value in the caller's environment wins.
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
@@ -361,10 +452,17 @@ def main() -> None:
     ap.add_argument("--payload", default="projected", choices=["projected", "encoder"],
                     help="N > 1: what the all-gather carries (3584-wide projected tokens / 1152-wide encoder tokens, "
                          "projector then runs on every rank)")
+    ap.add_argument("--no-session", action="store_true", help="skip the configs[3] multi-turn session timing")
+    ap.add_argument("--debug", default="", help="library debug switches for A/B runs: name=value[,name=value...] "
+                                                "(cogs_debug_set; `python -c 'from cogstream_amd import _lib; print(_lib.debug_list())'`)")
+    ap.add_argument("--vit-streams", type=int, default=2, choices=[1, 2],
+                    help="1: encode every clip on one stream (per-kernel profiles); 2 (default): two frame halves on two streams")
+    ap.add_argument("--no-ln-fold", action="store_true", help="A/B: LayerNorm as its own kernel instead of folded into the GEMMs")
     ap.add_argument("--emulate-shard", type=int, default=8,
                     help="N = 1 only: also time ONE rank's share (1/R of the frames) of the clip on this GPU and report "
                          "shard_efficiency = (t_clip / R) / t_shard (0 = off)")
     args = ap.parse_args()
+    t_process0 = time.perf_counter()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
@@ -398,6 +496,7 @@ def main() -> None:
                                        random_vit_state)
 
     vcfg, lcfg = VisionConfig(), LlmConfig()
+    debug_applied = L.debug_from_spec(args.debug)
     from cogstream_amd.parallel import frame_shards, gather_tokens
     from cogstream_amd.preprocess_gpu import preprocess_videos_gpu
     if args.config == "cfg5":
@@ -453,10 +552,11 @@ def main() -> None:
 
     # ---- weights (random, real dimensions) ----
     vit_state = random_vit_state(vcfg, seed=0, device=dev, dtype=torch.bfloat16)
-    enc = VisionEncoder(vit_state, vcfg, dtype=torch.bfloat16, device=dev)
+    enc = VisionEncoder(vit_state, vcfg, dtype=torch.bfloat16, device=dev, fold_ln=False if args.no_ln_fold else None)
     proj = Projector(random_proj_state(vcfg.hidden_size, lcfg.hidden_size, seed=1, device=dev, dtype=torch.bfloat16),
                      dtype=torch.bfloat16, device=dev)
     del vit_state
+    L.check(L.lib.cogs_vit_set_streams(enc.handle.h, args.vit_streams))
     wide = args.payload == "projected"
 
     def encode_step(clip, grid_full):
@@ -490,6 +590,7 @@ def main() -> None:
             dt_ = float(tt)
         return dt_, r
 
+    setup_s = time.perf_counter() - t_process0
     dt, mm = timed(step, args.warmup, args.steps)
     ms_per_step = dt / args.steps * 1e3
     fps = T * args.steps / dt
@@ -502,6 +603,7 @@ def main() -> None:
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak" if weak else "strong", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic", "ranks_seen": ranks_seen,
+        **({"debug_switches": debug_applied} if debug_applied else {}),
         "config": {"workload": f"{'cfg3 (BASELINE configs[2])' if cfg3 else ('cfg2 (BASELINE configs[1])' if T == 64 else 'cfg2-sized frames')}: "
                                f"{T}x480x854 '{args.clip}' clip -> {gh * 14}x{gw * 14}, "
                                f"{n_patches} patches, {m_tokens} visual tokens; ViT(1152x27, hd72)+projector(3584); "
@@ -516,6 +618,40 @@ def main() -> None:
                    "parallelism": (f"frames sharded over {world} GPUs ({t_loc} each), encode+project per rank, {gather_note}")
                    if world > 1 else "single GPU"},
     }
+
+    # ---- N > 1: the all-gather on its own, both payloads (events on the stream the collective is queued from + wall) ----
+    if world > 1:
+        from cogstream_amd.parallel import gather_rows
+        counts = [(e - b) * P for b, e in frame_shards(T, world)]
+        ag = {"backend": dist.get_backend(), "note": "the one data-path collective of a step, alone: all-gather of this clip's "
+              "visual tokens in frame order (parallel.gather_rows), MAX over ranks of the per-rank median of 10 calls, each "
+              "between two barriers; ms_events = HIP events around the call on the current stream (the RCCL kernel is "
+              "joined to it), ms_wall = host clock incl. launch" + ("; REHEARSAL on one GPU over gloo, staged through host "
+              "memory: not a link measurement" if rehearsal else "")}
+        for label, width in (("projected", lcfg.hidden_size), ("encoder", vcfg.hidden_size)):
+            loc = torch.randn(counts[rank], width, device=dev, dtype=torch.float32).to(torch.bfloat16)
+            for _ in range(3):
+                gather_rows(loc, counts)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tev, twall = [], []
+            for _ in range(10):
+                barrier()
+                t0 = time.perf_counter()
+                e0.record()
+                gather_rows(loc, counts)
+                e1.record()
+                torch.cuda.synchronize()
+                twall.append((time.perf_counter() - t0) * 1e3)
+                tev.append(e0.elapsed_time(e1))
+            med = torch.tensor([sorted(tev)[5], sorted(twall)[5]], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(med, op=dist.ReduceOp.MAX)
+            ag[label] = {"row_bytes": width * 2, "bytes_per_rank": counts[rank] * width * 2, "bytes_total": sum(counts) * width * 2,
+                         "ms_events": round(float(med[0]), 4), "ms_wall": round(float(med[1]), 4),
+                         "share_of_step": round(float(med[0]) / ms_per_step, 4)}
+            del loc
+        if rank == 0:
+            out["allgather"] = ag
+            out["allgather"]["payload_of_this_run"] = args.payload
 
     # ---- roofline of the dominant kernel (bf16 MFMA GEMM), HIP events around every launch ----
     # every rank runs this pass (it contains the all-gather); rank 0 reports its own kernels
@@ -702,6 +838,10 @@ def main() -> None:
             out["pipeline"]["cfg3"] = pipeline_once(model, processor, clip256, 64, expect_prompt=prompt_tokens(256, 50))
             out["pipeline"]["cfg3"]["clip"] = "drift (the noise clip keeps every token; drift prunes by pixel difference)"
             del clip256, model
+            if not args.no_session:
+                out["session"] = session_probe(
+                    lambda: CogReasoner(enc, proj, eng, lcfg, generation_config=dict(do_sample=False, eos_token_id=[])),
+                    processor, dev)
         del eng
         torch.cuda.empty_cache()
         # ---- CPU column for the token rate: the oracle's Qwen2 (torch fp32) decoding ONE token at the same context on
@@ -768,6 +908,8 @@ def main() -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        out["wall_s"] = {"setup_before_first_step": round(setup_s, 2), "rank_process_total": round(time.perf_counter() - t_process0, 2),
+                         "note": "seconds inside this rank process (interpreter start and `import torch` come before it)"}
         print(json.dumps(out), flush=True)
 
 

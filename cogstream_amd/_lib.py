@@ -8,7 +8,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 import os as _os
 
-LIB_PATH = Path(_os.environ.get("COGS_LIB_PATH", str(_HERE / "libcogs_hip.so")))  # override: A/B experiments only
+LIB_PATH = Path(_os.environ.get("COGS_LIB_PATH", str(_HERE / "libcogs_hip.so")))  # another BUILD of the library (tools/build_alt.sh)
 
 DT_BF16, DT_F32 = 0, 1
 OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_WORKSPACE = 0, -1, -2, -3, -4      # cogs_status (include/cogs.h)
@@ -117,6 +117,9 @@ class KV(C.Structure):
 SIGNATURES = {
     "cogs_status_string": (C.c_char_p, [c_int]),
     "cogs_version": (C.c_char_p, []),
+    "cogs_debug_set": (c_int, [C.c_char_p, c_int64]),
+    "cogs_debug_get": (c_int, [C.c_char_p, C.POINTER(c_int64)]),
+    "cogs_debug_list": (C.c_char_p, []),
     "cogs_create": (c_int, [c_int, C.POINTER(c_void_p)]),
     "cogs_destroy": (c_int, [c_void_p]),
     "cogs_vit_set_streams": (c_int, [c_void_p, c_int]),
@@ -183,6 +186,58 @@ def check(status: int, what: str = "") -> None:
     if status != 0:
         msg = lib.cogs_status_string(status).decode()
         raise CogsError(f"{what or 'cogs call'} failed: {msg} ({status})")
+
+
+def debug_set(name: str, value: int) -> None:
+    """one diagnostic switch of the library (csrc/debug.h; `debug_list()` prints the table)"""
+    check(lib.cogs_debug_set(name.encode(), int(value)), f"cogs_debug_set({name})")
+
+
+def debug_get(name: str) -> int:
+    v = c_int64(0)
+    check(lib.cogs_debug_get(name.encode(), C.byref(v)), f"cogs_debug_get({name})")
+    return int(v.value)
+
+
+def debug_list() -> str:
+    return lib.cogs_debug_list().decode()
+
+
+class debug_switch:
+    """with debug_switch("gemm_pp64", 0): ...   -- sets a switch and restores the previous value on exit"""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = debug_get(self.name)
+        debug_set(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        debug_set(self.name, self.old)
+        return False
+
+
+def debug_from_spec(spec: str) -> dict:
+    """"name=value[,name=value...]" -> applied switches (bench.py --debug, tools/*)"""
+    done = {}
+    for item in filter(None, (x.strip() for x in spec.split(","))):
+        k, _, v = item.partition("=")
+        debug_set(k.strip(), int(v))
+        done[k.strip()] = int(v)
+    return done
+
+
+def debug_from_argv(argv: list) -> dict:
+    """strip every `--debug name=value[,...]` pair out of argv (in place) and apply it: lets any tool run under an A/B
+    switch without its own option parsing"""
+    done = {}
+    while "--debug" in argv:
+        i = argv.index("--debug")
+        done.update(debug_from_spec(argv[i + 1]))
+        del argv[i:i + 2]
+    return done
 
 
 def dtype_code(torch_dtype) -> int:

@@ -21,6 +21,7 @@
 // fp32 / generic kernel: one wave per (query row, head), two passes; parity mode only.
 #include "common.h"
 #include "kernels.h"
+#include "debug.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1290,14 +1291,14 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
     p.q_pos0 = a.q_pos0; p.causal = a.causal;
     const int nseg = a.cu_seqlens ? a.nseg : 1;
     p.nsplit = 1; p.gqa_pack = 0; p.q_prescaled = 0; p.part_o = nullptr; p.part_ml = nullptr;
-    static const bool env_light_first = getenv("COGS_ATTN_LIGHT_FIRST") && atoi(getenv("COGS_ATTN_LIGHT_FIRST")) == 1;   // A/B runs only
+    const bool env_light_first = g_cogs_debug.attn_light_first == 1;   // A/B runs only
     p.heavy_first = (a.causal && !a.cu_seqlens && a.q_len > 128 && !env_light_first) ? 1 : 0;
-    static const int env_prio = getenv("COGS_ATTN_PRIO") ? atoi(getenv("COGS_ATTN_PRIO")) : 2;   // in-run A/B at 15 395 tokens: 0 / 1 / 2 = 1.90-1.91 / 1.88-1.89 / 1.83 ms per layer
+    const int env_prio = (int)g_cogs_debug.attn_prio;   // in-run A/B at 15 395 tokens: 0 / 1 / 2 = 1.90-1.91 / 1.88-1.89 / 1.83 ms per layer
     p.prio_mode = env_prio;
-    static const int env_pp_prio = getenv("COGS_ATTN_PP_PRIO") ? atoi(getenv("COGS_ATTN_PP_PRIO")) : 1;
+    const int env_pp_prio = (int)g_cogs_debug.attn_pp_prio;
     p.pp_prio = env_pp_prio;
     // the encoder's production shape (per-frame segments, hd 72, pre-scaled Q, no masks) has its own kernel
-    static const bool env_old_vit = getenv("COGS_ATTN_VIT") && atoi(getenv("COGS_ATTN_VIT")) == 0;   // A/B runs only
+    const bool env_old_vit = g_cogs_debug.attn_vit == 0;   // A/B runs only
     if (a.dtype == COGS_DT_BF16 && !a.force_rowwise && a.head_dim == 72 && a.q_prescaled && a.cu_seqlens && !a.row_lo &&
         !a.causal && a.nsplit <= 1 && a.hq == a.hkv && a.ldo % 8 == 0 && !env_old_vit)
         return cogs_k_attention_vit(st, a);
@@ -1316,7 +1317,7 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
         }
         if (a.q_len == 1 && a.hq / a.hkv <= 16 && !a.cu_seqlens) { p.gqa_pack = 1; gy = a.hkv; }
         dim3 grid(qtiles * p.nsplit, gy, nseg);
-        static const int env_nq = getenv("COGS_ATTN_NQ") ? atoi(getenv("COGS_ATTN_NQ")) : 0;
+        const int env_nq = (int)g_cogs_debug.attn_nq;
         // 8 waves x 16 rows: measured faster for hd 128 (no spills, 4 waves per SIMD: causal prefill 2.58 -> 2.29 ms
         // at 15k tokens), slower for hd 72 (0.49 -> 0.52 ms: its fragment reads make the LDS the busiest unit)
         // (with pre-scaled Q the 4-wave hd 128 kernel needs 243 VGPRs and no longer spills: 2.34 -> 2.26 ms, so the
@@ -1331,15 +1332,15 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
         else hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD_, NQ_, false>), grid, dim3(NT_), 0, st, p);             \
     } while (0)
         // the generated tokens' attention (one query row, key-split) has its own kernel: every wave owns whole tiles
-        static const bool env_old_dec = getenv("COGS_ATTN_DECODE") && atoi(getenv("COGS_ATTN_DECODE")) == 0;   // A/B runs only
-        static const bool env_no_dma = getenv("COGS_ATTN_PREFILL_DMA") && atoi(getenv("COGS_ATTN_PREFILL_DMA")) == 0;   // A/B runs only
+        const bool env_old_dec = g_cogs_debug.attn_decode == 0;   // A/B runs only
+        const bool env_no_dma = g_cogs_debug.attn_prefill_dma == 0;   // A/B runs only
         if (a.head_dim == 128 && pre && a.causal && p.nsplit == 1 && !p.gqa_pack && !a.row_lo && !env_no_dma && a.q_len >= 128 &&
             a.ldo % 8 == 0) {
             // the ping-pong form (attn_prefill_pp_kernel) is built, bit-identical and measured: 1.89 ms against 1.81-1.86 ms
             // per layer at 15 395 tokens on the same box -- both kernels sit at ~2 000 shader cycles per wave and tile for
             // 1 024 cycles of MFMA, because every K / V fragment read from LDS feeds only two MFMAs (32 query rows per
-            // wave): 48 LDS reads per 64 MFMAs. Off by default; COGS_ATTN_PREFILL_PP=1 selects it.
-            static const bool env_pp = getenv("COGS_ATTN_PREFILL_PP") && atoi(getenv("COGS_ATTN_PREFILL_PP")) == 1;
+            // wave): 48 LDS reads per 64 MFMAs. Off by default; debug switch attn_prefill_pp = 1 selects it.
+            const bool env_pp = g_cogs_debug.attn_prefill_pp == 1;
             if (env_pp && max_len >= 256) {
                 static std::atomic<uint64_t> attr_done{0};
                 cogs_ensure_dyn_lds((const void*)attn_prefill_pp_kernel, 5 * 32 * 1024, attr_done);
@@ -1349,6 +1350,7 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
                 (void)hipMemsetAsync(dbg, 0, 32 * 8, st);
                 p.part_o = reinterpret_cast<float*>(dbg);
 #endif
+                g_cogs_debug.attn_last_kernel = 6;
                 hipLaunchKernelGGL(attn_prefill_pp_kernel, dim3((max_len + 255) / 256, gy, nseg), dim3(512), 5 * 32 * 1024, st, p);
 #ifdef COGS_ATTN_PP_STAMPS
                 {
@@ -1364,15 +1366,19 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
                 }
 #endif
             } else {
+                g_cogs_debug.attn_last_kernel = 5;
                 hipLaunchKernelGGL(attn_prefill_dma_kernel, grid, dim3(256), 0, st, p);
             }
         } else if (a.head_dim == 128 && a.q_len == 1 && p.nsplit > 1 && p.gqa_pack && pre && !env_old_dec) {
             const int rc = cogs_k_attention_decode(st, a, p.part_o, p.part_ml);
             if (rc != COGS_OK) return rc;
+            g_cogs_debug.attn_last_kernel = 4;
         } else if (a.head_dim == 72) {
+            g_cogs_debug.attn_last_kernel = 1;
             if (light && !p.gqa_pack) COGS_ATTN_LAUNCH(72, 1, 512);
             else COGS_ATTN_LAUNCH(72, 2, 256);
         } else {
+            g_cogs_debug.attn_last_kernel = 1;
             if (light && !p.gqa_pack) COGS_ATTN_LAUNCH(128, 1, 512);
             else COGS_ATTN_LAUNCH(128, 2, 256);
         }
@@ -1383,6 +1389,7 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
         return COGS_LAUNCH_CHECK();
     }
     dim3 grid(a.q_len, a.hq);
+    g_cogs_debug.attn_last_kernel = 7;
     if (a.dtype == COGS_DT_BF16)
         hipLaunchKernelGGL(attn_rowwise_kernel<bf16_t>, grid, dim3(64), 0, st, p, a.head_dim, nseg);
     else

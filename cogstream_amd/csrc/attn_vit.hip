@@ -25,6 +25,7 @@
 //     four different 64-B bank quarters for the transposing read). 46 KiB per workgroup: 3 workgroups per CU.
 #include "common.h"
 #include "kernels.h"
+#include "debug.h"
 #include <stdlib.h>
 
 namespace {
@@ -780,10 +781,10 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     p.uniform_len = (a.uniform_seqlen > 0 && (long)a.uniform_seqlen * a.nseg == a.q_len && a.uniform_seqlen == a.max_seqlen) ? a.uniform_seqlen : 0;
     if ((long)p.nseg * p.heads * p.nqb > 0x7fffffffL) return COGS_E_INVALID;
     dim3 grid(p.nseg * p.heads * p.nqb);
-    static const int variant = getenv("COGS_ATTN_VIT") ? atoi(getenv("COGS_ATTN_VIT")) : 2;     // 1: unpipelined (A/B runs)
-    static const int env_early = getenv("COGS_AV_EARLY") ? atoi(getenv("COGS_AV_EARLY")) : 0;
+    const int variant = (int)g_cogs_debug.attn_vit;     // 1: unpipelined (A/B runs)
+    const int env_early = (int)g_cogs_debug.attn_vit_early;
     p.early_prefetch = env_early;
-    if (variant == 1 || a.ldk != a.ldv) hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(attn_vit_pipe_kernel<72>, grid, dim3(256), 0, st, p);
+    if (variant == 1 || a.ldk != a.ldv) { g_cogs_debug.attn_last_kernel = 2; hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p); }
+    else { g_cogs_debug.attn_last_kernel = 3; hipLaunchKernelGGL(attn_vit_pipe_kernel<72>, grid, dim3(256), 0, st, p); }
     return COGS_LAUNCH_CHECK();
 }

@@ -4,6 +4,7 @@
 #include "../../include/cogs.h"
 #include "common.h"
 #include "kernels.h"
+#include "debug.h"
 
 #include <math.h>
 #include <stdint.h>
@@ -13,6 +14,8 @@
 #include <atomic>
 #include <string.h>
 #include <vector>
+
+CogsDebug g_cogs_debug;
 
 struct cogs_ctx {
     int device = 0;
@@ -149,6 +152,36 @@ const char* cogs_status_string(cogs_status s) {
 }
 
 const char* cogs_version(void) { return "cogstream_amd 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------- diagnostics (csrc/debug.h)
+cogs_status cogs_debug_set(const char* name, int64_t value) {
+    if (!name) return COGS_E_INVALID;
+#define COGS_DBG_SET(n, dflt, doc) if (strcmp(name, #n) == 0) { g_cogs_debug.n = value; return COGS_OK; }
+    COGS_DEBUG_SWITCHES(COGS_DBG_SET)
+#undef COGS_DBG_SET
+    return COGS_E_INVALID;
+}
+
+cogs_status cogs_debug_get(const char* name, int64_t* value) {
+    if (!name || !value) return COGS_E_INVALID;
+#define COGS_DBG_GET(n, dflt, doc) if (strcmp(name, #n) == 0) { *value = g_cogs_debug.n; return COGS_OK; }
+    COGS_DEBUG_SWITCHES(COGS_DBG_GET)
+#undef COGS_DBG_GET
+    if (strcmp(name, "gemm_last_body") == 0) { *value = g_cogs_debug.gemm_last_body; return COGS_OK; }
+    if (strcmp(name, "attn_last_kernel") == 0) { *value = g_cogs_debug.attn_last_kernel; return COGS_OK; }
+    return COGS_E_INVALID;
+}
+
+const char* cogs_debug_list(void) {
+    return
+#define COGS_DBG_DOC(n, dflt, doc) #n " = " #dflt ": " doc "\n"
+        COGS_DEBUG_SWITCHES(COGS_DBG_DOC)
+#undef COGS_DBG_DOC
+        "gemm_last_body (read only): body the last cogs_gemm dispatched to -- 1 128x128, 2 256x128 ring, 3 K-tile ping-pong, "
+        "4 whole-line ping-pong, 5 ping-pong + ring (split launch), 6 GEMV\n"
+        "attn_last_kernel (read only): kernel of the last cogs_attention -- 1 general MFMA, 2 ViT unpipelined, 3 ViT pipelined, "
+        "4 single-token decode, 5 prompt LDS-DMA, 6 prompt ping-pong, 7 row-wise fp32, 8 ViT pipelined on head-major K/V\n";
+}
 
 cogs_status cogs_create(int device, cogs_handle* out) {
     if (!out) return COGS_E_INVALID;
@@ -437,8 +470,7 @@ static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* p
 // share of a frame-sharded clip (8 frames of 22 x 42 patches: 145 tiles for the N = 1152 shapes) gains 10 %, the whole
 // 64-frame clip 2.7 % (round 4, same box, interleaved: 60.8 -> 59.2 ms; 256 frames at 140 x 280: 47.3 -> 46.5 ms).
 // Not while the per-kernel profiler is on: overlapping launches stretch every bracket, so bench.py's `roofline` and
-// `breakdown_ms` describe the kernels one at a time. COGS_VIT_STREAMS=1 or COGS_VIT_SPLIT_MAX=<patches> switch it off.
-static const int64_t VIT_SPLIT_MAX_PATCHES = (int64_t)1 << 40;
+// `breakdown_ms` describe the kernels one at a time. cogs_vit_set_streams(h, 1) or the debug switch vit_split_max switch it off.
 
 cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
                             const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
@@ -452,9 +484,8 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
         N += t * gh * gw;
         nframes += t;
     }
-    static const bool env_single = getenv("COGS_VIT_STREAMS") && atoi(getenv("COGS_VIT_STREAMS")) == 1;
-    static const int64_t split_max = getenv("COGS_VIT_SPLIT_MAX") ? atoll(getenv("COGS_VIT_SPLIT_MAX")) : VIT_SPLIT_MAX_PATCHES;
-    if (!env_single && h->vit_streams > 1 && !h->prof_on && attn_mode == COGS_ATTN_BLOCK_DIAG && nframes >= 2 && N <= split_max) {
+    const int64_t split_max = g_cogs_debug.vit_split_max;
+    if (h->vit_streams > 1 && !h->prof_on && attn_mode == COGS_ATTN_BLOCK_DIAG && nframes >= 2 && N <= split_max) {
         // cut at the frame boundary nearest to half the patches
         std::vector<int64_t> ga, gb, ma, mb;
         int64_t rows_a = 0, toks_a = 0, fa = 0, best_gap = N + 1, acc = 0;
@@ -751,7 +782,7 @@ static int llm_nsplit(int ctx) {
     // context 2 048: 256: 3.51, 128: 3.42, 64: 3.39 -- i.e. at least ~32 splits, of 64..256 keys
     // => at least 32 splits while a split keeps 64 keys, 256 keys per split beyond that (monotonic in ctx: the
     // workspace is sized with the largest context)
-    static const int env_keys = getenv("COGS_LLM_SPLIT_KEYS") ? atoi(getenv("COGS_LLM_SPLIT_KEYS")) : 0;
+    const int env_keys = (int)g_cogs_debug.llm_split_keys;
     int n;
     if (env_keys > 0) n = (ctx + env_keys - 1) / env_keys;
     else {

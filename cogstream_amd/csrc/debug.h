@@ -1,0 +1,54 @@
+// Diagnostic switches of libcogs_hip.so: ONE table, changed only through cogs_debug_set (include/cogs.h).
+//
+// Nothing in the library reads the environment. Every entry below has the SHIPPED behaviour as its default; the
+// measurement tools (bench.py --debug, tools/*) and the A/B tests flip an entry by name, run, and flip it back -- in one
+// process, so both sides of a comparison run on the same device (rounds 1-4 read ~28 COGS_* environment variables into
+// function-local statics spread over the kernel files; a value could only be chosen before the first call).
+// The table is process-wide and unsynchronised: set a switch between calls, not beside a running call on another thread.
+#pragma once
+
+//   X(name, default, meaning)
+#define COGS_DEBUG_SWITCHES(X)                                                                                              \
+    /* ---- GEMM (csrc/gemm.hip) ---- */                                                                                    \
+    X(gemm_pp64, 1, "1: whole-line ping-pong kernel (gemm_tn_pp64_kernel); 0: the 32-wide K-tile body it replaced")         \
+    X(gemm_pingpong, 1, "0: never take a ping-pong kernel (256x128 ring / 128x128 kernels only)")                          \
+    X(gemm_small, 0, "1: always the 128x128 kernel")                                                                        \
+    X(gemm_wgs, 256, "persistent workgroups of the 256x128 ring kernel (0: one tile per workgroup)")                        \
+    X(gemm_pad_pct, 112, "ping-pong kernel is taken while N padded to 256 <= this percentage of N")                         \
+    X(gemm_rope_lut, 1, "K-tile body only: rotary factors from the LDS position LUT when the caller supplies one")          \
+    X(gemm_group_m, 0, "> 0: row blocks per group of the ping-pong tile walk (0: chosen per shape)")                        \
+    X(gemm_split, 1, "0: no round-aligned / few-tile split of a launch")                                                    \
+    X(gemm_co_streams, 0, "> 0: overrides the co-running-streams hint of the few-tile choice")                              \
+    X(gemm_ring_cost_permille, 720, "few-tile choice: cost of a round of ring tiles relative to a round of ping-pong tiles") \
+    X(gemm_epi_serial, 0, "1: the two wave groups' epilogues in separate intervals (the order before round 4)")             \
+    X(gemm_nostore, 0, "1: timing only -- K loops without epilogues (results are NOT written)")                             \
+    X(gemm_trace, 0, "1: per-tile s_memtime stamps of workgroup 0 printed to stderr (synchronises)")                        \
+    X(gemm_choice, 0, "1: print which body every ping-pong-eligible shape gets")                                            \
+    X(gemm_headmajor, 1, "ViT encode: QKV GEMM writes q/k/v head-major [which][head][row][hd] for the attention kernel")    \
+    /* ---- attention (csrc/attn.hip, attn_vit.hip, attn_decode.hip) ---- */                                                \
+    X(attn_vit, 2, "ViT block-diagonal attention: 2 pipelined LDS-DMA kernel, 1 unpipelined, 0 general kernel")            \
+    X(attn_vit_early, 0, "1: pipelined ViT kernel issues tiles 1-2 before its first wait (the order before round 4)")       \
+    X(attn_decode, 1, "0: single-token attention through the general split-KV kernel")                                      \
+    X(attn_prefill_dma, 1, "0: Qwen2 prompt attention through the general register-staged kernel")                          \
+    X(attn_prefill_pp, 0, "1: ping-pong form of the prompt attention (bit-identical, measured slower)")                     \
+    X(attn_prio, 2, "prompt attention wave priorities: 0 none, 1 MFMA phases raised, 2 softmax phase raised")               \
+    X(attn_pp_prio, 1, "ping-pong prompt attention: 1 priority raised in the MFMA group")                                   \
+    X(attn_light_first, 0, "1: causal query tiles issued lightest first")                                                   \
+    X(attn_nq, 0, "general kernel: 1 / 2 forces 16 / 32 query rows per wave")                                              \
+    /* ---- encoder / LLM drivers (csrc/capi.hip), k-means ---- */                                                          \
+    X(vit_split_max, 1099511627776LL, "clips above this many patches are encoded on one stream")                           \
+    X(llm_split_keys, 0, "> 0: keys per split of the decode attention (0: chosen from the context)")                        \
+    X(km_row_groups, 0, "> 0: row groups of the k-means distance pass (0: sized to fill the chip)")
+
+struct CogsDebug {
+#define COGS_DBG_FIELD(name, dflt, doc) long long name = dflt;
+    COGS_DEBUG_SWITCHES(COGS_DBG_FIELD)
+#undef COGS_DBG_FIELD
+    // read-only reports (cogs_debug_get): what the last cogs_gemm of this process dispatched to
+    // 0 none yet, 1 128x128, 2 256x128 ring, 3 K-tile ping-pong, 4 whole-line ping-pong, 5 ping-pong + ring (split), 6 GEMV
+    long long gemm_last_body = 0;
+    // ... and the last cogs_attention: 1 general MFMA kernel, 2 ViT unpipelined, 3 ViT pipelined (row-major K/V), 4 single-token
+    // decode (+ combine), 5 prompt LDS-DMA kernel, 6 prompt ping-pong kernel, 7 row-wise fp32 kernel, 8 ViT pipelined, head-major K/V
+    long long attn_last_kernel = 0;
+};
+extern CogsDebug g_cogs_debug;     // capi.hip

@@ -25,6 +25,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "gemm_epilogue.h"
+#include "debug.h"
 #include <stdlib.h>
 
 namespace {
@@ -46,8 +47,8 @@ struct GemmArgs {
     int nbm, nbn;
     const float* rope_lut; int rope_lut_bytes;   // EPI_ROPE_LUT: global LUT copied to LDS behind the ring at kernel start
     int group_m;                 // ping-pong kernel: row blocks per group of the tile walk (L2 footprint of an XCD)
-    int epi_serial;              // whole-line kernel, A/B runs (COGS_GEMM_EPISERIAL=1): both groups' epilogues behind the tile's last barrier
-    unsigned long long* trace;   // diagnostics (COGS_GEMM_TRACE): per-tile s_memtime stamps of WG 0, waves 0 and 4
+    int epi_serial;              // whole-line kernel, A/B runs (debug switch gemm_epi_serial): both groups' epilogues behind the tile's last barrier
+    unsigned long long* trace;   // diagnostics (debug switch gemm_trace): per-tile s_memtime stamps of WG 0, waves 0 and 4
     EpiArgs epi;
 };
 
@@ -905,6 +906,7 @@ void launch_small(hipStream_t st, const GemmArgs& p, int grid) {
     static std::atomic<uint64_t> attr_done{0};
     cogs_ensure_dyn_lds((const void*)gemm_tn_kernel<T, EPI>, (int)lds, attr_done);
     ++g_gemm_launches;
+    g_cogs_debug.gemm_last_body = 1;
     hipLaunchKernelGGL((gemm_tn_kernel<T, EPI>), dim3(grid), dim3(256), lds, st, p);
 }
 template <typename T, int EPI>
@@ -912,24 +914,22 @@ void launch_big(hipStream_t st, const GemmArgs& p, int grid) {
     const size_t lds = 3 * SLAB2;
     static std::atomic<uint64_t> attr_done{0};
     cogs_ensure_dyn_lds((const void*)gemm_tn_256x128_kernel<T, EPI>, (int)lds, attr_done);
-    static const int env_wgs = getenv("COGS_GEMM_WGS") ? atoi(getenv("COGS_GEMM_WGS")) : PERSISTENT_WGS;
-    const int wgs = env_wgs <= 0 ? grid : (grid < env_wgs ? grid : env_wgs);   // 0 = one tile per workgroup
+    const int dbg_wgs = (int)g_cogs_debug.gemm_wgs;
+    const int wgs = dbg_wgs <= 0 ? grid : (grid < dbg_wgs ? grid : dbg_wgs);   // 0 = one tile per workgroup
     ++g_gemm_launches;
+    g_cogs_debug.gemm_last_body = 2;
     hipLaunchKernelGGL((gemm_tn_256x128_kernel<T, EPI>), dim3(wgs), dim3(512), lds, st, p);
 }
-// COGS_GEMM_PP64=0 keeps the 32-wide K-tile kernel (A/B runs); default: the whole-line kernel wherever it exists (every
-// epilogue but the rotary LUT one, for which it has no LDS left -- cogs_k_gemm then takes the rotary factors from global
-// memory instead: measured 1 % faster end to end than the LUT epilogue on the old body)
-bool pp64_enabled() {
-    static const bool on = !getenv("COGS_GEMM_PP64") || atoi(getenv("COGS_GEMM_PP64")) != 0;
-    return on;
-}
+// debug switch gemm_pp64 = 0 keeps the 32-wide K-tile kernel (A/B runs); default: the whole-line kernel wherever it exists
+// (every epilogue but the rotary LUT one, for which it has no LDS left -- cogs_k_gemm then takes the rotary factors from
+// global memory instead: measured 1 % faster end to end than the LUT epilogue on the old body)
+bool pp64_enabled() { return g_cogs_debug.gemm_pp64 != 0; }
 template <int EPI>
 void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
     const size_t lds = RING3 * SLOT3 + ((EPI & EPI_ROPE_LUT) ? 28 * 1024 : 0);   // ring (+ rotary LUT, <= 28 KiB)
     static std::atomic<uint64_t> attr_done{0};
     cogs_ensure_dyn_lds((const void*)gemm_tn_pp_kernel<EPI>, (int)lds, attr_done);
-    static const bool env_trace = getenv("COGS_GEMM_TRACE") != nullptr;
+    const bool env_trace = g_cogs_debug.gemm_trace != 0;
     if (env_trace) {
         static unsigned long long* dbuf = nullptr;
         if (!dbuf) (void)hipMalloc(&dbuf, 224 * 8);
@@ -981,10 +981,12 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         if (env_pp64 && p.K >= 128) {
             static std::atomic<uint64_t> attr_done64{0};
             cogs_ensure_dyn_lds((const void*)gemm_tn_pp64_kernel<EPI>, RING4 * UNIT4, attr_done64);
+            g_cogs_debug.gemm_last_body = 4;
             hipLaunchKernelGGL((gemm_tn_pp64_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), RING4 * UNIT4, st, p);
             return;
         }
     }
+    g_cogs_debug.gemm_last_body = 3;
     hipLaunchKernelGGL((gemm_tn_pp_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), lds, st, p);
 }
 void dispatch_pp(hipStream_t st, const GemmArgs& p, int grid, int mask) {
@@ -1047,32 +1049,31 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     // the fused-LayerNorm features exist in the specialised MFMA epilogues only: the single-row GEMV and the run-time
     // (EPI_GENERIC) epilogue know neither, and silently dropping them would return un-normalised rows
     if ((g.row_stats || g.ln_ab) && (g.M == 1 || cogs_epi_mask(g) == EPI_GENERIC)) return COGS_E_UNSUPPORTED;
-    if (g.M == 1) { ++g_gemm_launches; return cogs_k_gemv(st, g); }
+    if (g.M == 1) { ++g_gemm_launches; g_cogs_debug.gemm_last_body = 6; return cogs_k_gemv(st, g); }
     if (g.rms_gamma) return COGS_E_UNSUPPORTED;   // fused RMSNorm exists for the single-token GEMV only
     GemmArgs p;
     p.trace = nullptr; p.rope_lut = nullptr; p.rope_lut_bytes = 0; p.group_m = GROUP_M;
-    static const int env_epi_serial = getenv("COGS_GEMM_EPISERIAL") ? atoi(getenv("COGS_GEMM_EPISERIAL")) : 0;
-    p.epi_serial = env_epi_serial;
+    p.epi_serial = (int)g_cogs_debug.gemm_epi_serial;
     const int rc = cogs_fill_epi(g, &p.epi);
     if (rc != COGS_OK) return rc;
     p.A = (const char*)g.A; p.lda = g.lda * es;
     p.W = (const char*)g.W; p.ldw = g.ldw * es;
     p.M = g.M; p.N = g.N; p.K = g.K;
-    static const bool env_small = getenv("COGS_GEMM_SMALL") != nullptr;
-    static const bool env_nopp = getenv("COGS_GEMM_NOPP") != nullptr;
+    const bool env_small = g_cogs_debug.gemm_small != 0;
+    const bool env_nopp = g_cogs_debug.gemm_pingpong == 0;
     const int n_pad = (g.N + BN3 - 1) / BN3 * BN3;
-    static const int env_waste = getenv("COGS_GEMM_PPWASTE") ? atoi(getenv("COGS_GEMM_PPWASTE")) : 112;
+    const int env_waste = (int)g_cogs_debug.gemm_pad_pct;
     const bool pp_fits = n_pad * 100 <= g.N * env_waste;   // default: <= 12 % of the MFMAs spent on N padding (N = 1152 -> 1280 measured faster than the 256x128 ring kernel)
     if (!env_nopp && !env_small && g.dtype == COGS_DT_BF16 && g.M >= 1024 && pp_fits && !g.force_small_tile &&
         !g.force_mid_tile) {
         p.nbm = (g.M + BM3 - 1) / BM3;
         p.nbn = (g.N + BN3 - 1) / BN3;
-        static const bool env_nostore = getenv("COGS_GEMM_NOSTORE") != nullptr;
-        static const bool env_nolut = getenv("COGS_GEMM_NOLUT") != nullptr;
+        const bool env_nostore = g_cogs_debug.gemm_nostore != 0;
+        const bool env_nolut = g_cogs_debug.gemm_rope_lut == 0;
         // tile walk: groups of group_m row blocks x all column blocks. Measured (in-run A/B, cfg2 shapes): few column
         // blocks with a long K (fc2: 5 x K 4352) want small groups (2: 0.627 -> 0.591 ms), many column blocks with a
         // short K (fc1: 17 x K 1152) want 8 (2: +7 %)
-        static const int env_gm = getenv("COGS_GEMM_GROUPM") ? atoi(getenv("COGS_GEMM_GROUPM")) : 0;
+        const int env_gm = (int)g_cogs_debug.gemm_group_m;
         p.group_m = env_gm > 0 ? env_gm : ((p.nbn <= 6 && g.K >= 2048) ? 2 : GROUP_M);
         int pp_mask = cogs_epi_mask(g);
         p.rope_lut = nullptr; p.rope_lut_bytes = 0;
@@ -1089,13 +1090,13 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         // leading row blocks that make up WHOLE rounds stay here and the remaining rows go to the 256x128 kernel,
         // whose half-size tiles fill the chip again (rows are independent: same arithmetic per row, same K order, so
         // a row's result does not depend on which kernel computed it).
-        static const bool env_nosplit = getenv("COGS_GEMM_NOSPLIT") != nullptr;
+        const bool env_nosplit = g_cogs_debug.gemm_split == 0;
         const int nb = p.nbm * p.nbn;
         const int rounds = nb / PERSISTENT_WGS, rem = nb % PERSISTENT_WGS;
         int mb_main = -1;      // >= 0: row blocks that stay in this kernel (0 = none: the whole GEMM goes to the ring kernel)
         // (calibrated on K = 1152 .. 4352, the ViT shapes; longer K -- the Qwen2 prompt pass at M = 2048 -- keeps the
         // plain ping-pong launch)
-        static const int env_co = getenv("COGS_GEMM_COSTREAMS") ? atoi(getenv("COGS_GEMM_COSTREAMS")) : 0;   // A/B runs
+        const int env_co = (int)g_cogs_debug.gemm_co_streams;   // A/B runs
         const int S = env_co > 0 ? env_co : g_co_streams;
         if (!env_nosplit && !env_nostore && nb <= 2 * PERSISTENT_WGS && g.K <= 4352) {
             // Few tiles (one rank's share of a frame-sharded clip: M = 6 400 is 125 tiles for N = 1152 and 350 = 1.37
@@ -1112,7 +1113,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
                 return S == 1 ? (float)((tiles + PERSISTENT_WGS - 1) / PERSISTENT_WGS)
                               : fmaxf(1.f, (float)S * (float)tiles / (float)PERSISTENT_WGS);
             };
-            static const float c_ring = getenv("COGS_GEMM_CRING") ? (float)atof(getenv("COGS_GEMM_CRING")) : 0.72f;   // env: calibration sweeps
+            const float c_ring = (float)g_cogs_debug.gemm_ring_cost_permille * 1e-3f;   // 0.72; the switch is for calibration sweeps
             const float c_launch = 0.08f;
             const float cost_pp = launch_cost(nb);
             const float cost_ring = c_ring * launch_cost(rbm * rbn);
@@ -1133,7 +1134,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
             const int mb = rounds * PERSISTENT_WGS / p.nbn;          // whole row blocks within the full rounds
             if (mb > 0 && g.M - mb * BM3 >= 512) mb_main = mb;
         }
-        static const bool env_choice = getenv("COGS_GEMM_CHOICE") != nullptr;      // diagnostics: which body each shape gets
+        const bool env_choice = g_cogs_debug.gemm_choice != 0;      // diagnostics: which body each shape gets
         if (env_choice) fprintf(stderr, "[gemm choice] M=%d N=%d K=%d: %d ping-pong tiles (%d rounds + %d), mb_main %d\n", g.M, g.N, g.K, nb, rounds, rem, mb_main);
         if (mb_main >= 0) {
             const int rows_main = mb_main * BM3;
@@ -1156,7 +1157,9 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
                 const int rc2 = COGS_LAUNCH_CHECK();
                 if (rc2 != COGS_OK) return rc2;
             }
-            return cogs_k_gemm(st, b);
+            const int rc3 = cogs_k_gemm(st, b);
+            if (mb_main > 0) g_cogs_debug.gemm_last_body = 5;
+            return rc3;
         }
         dispatch_pp(st, p, nb, env_nostore ? EPI_NOSTORE : pp_mask);
         return COGS_LAUNCH_CHECK();

@@ -24,6 +24,7 @@
 // 512-column slice, fp64 across slices: DESIGN.md section 2 (near-tie study) says why not |x|^2 + |c|^2 - 2 x.c.
 #include "common.h"
 #include "kernels.h"
+#include "debug.h"
 #include <stdlib.h>
 
 namespace {
@@ -690,7 +691,7 @@ void launch_sqdist(hipStream_t st, const void* feats, int Tn, long PD, const flo
     // 700 workgroups 84 us, 1 050 -> 103 us, 1 400 -> 80 us) -- with at least 16 rows each
     const int per_cu = 80 / kp < 1 ? 1 : (80 / kp > 8 ? 8 : 80 / kp);
     int rg = 256 * per_cu / nslices;
-    static const int env_rg = getenv("COGS_KM_RG") ? atoi(getenv("COGS_KM_RG")) : 0;     // experiments
+    const int env_rg = (int)g_cogs_debug.km_row_groups;     // experiments
     if (env_rg > 0) rg = env_rg;
     rg = rg < 1 ? 1 : (rg > 8 ? 8 : rg);
     while (rg > 1 && (Tn + rg - 1) / rg < 16) --rg;

@@ -152,10 +152,13 @@ def frame_mean_to_slot0(feats: torch.Tensor, P: int, frames: torch.Tensor) -> No
                                          ptr(frames), frames.numel()), "cogs_frame_mean_to_slot0")
 
 
-def gather_rows(table_a: torch.Tensor, table_b: Optional[torch.Tensor], idx: torch.Tensor) -> torch.Tensor:
-    _need_cuda(table_a, table_b, idx)
+def gather_rows(table_a: torch.Tensor, table_b: Optional[torch.Tensor], idx: torch.Tensor,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(table_a, table_b, idx, out)
     assert idx.dtype == torch.int64 and table_a.is_contiguous()
-    out = torch.empty(idx.numel(), table_a.shape[1], device=table_a.device, dtype=table_a.dtype)
+    if out is None:
+        out = torch.empty(idx.numel(), table_a.shape[1], device=table_a.device, dtype=table_a.dtype)
+    assert out.is_contiguous() and out.shape == (idx.numel(), table_a.shape[1]) and out.dtype == table_a.dtype
     check(L.lib.cogs_gather_rows(current_stream(), dtype_code(table_a.dtype), ptr(table_a), ptr(table_b), ptr(idx),
                                  ptr(out), idx.numel(), table_a.shape[1]), "cogs_gather_rows")
     return out

@@ -24,13 +24,10 @@ class VisionEncoder:
     def __init__(self, state: Dict[str, torch.Tensor], cfg: VisionConfig, dtype=torch.bfloat16, device="cuda",
                  attn_mode: int = BLOCK_DIAG, fold_ln=None):
         """fold_ln: None = the default of weights.PackedVit (LayerNorm folded into the QKV / fc1 GEMMs in bf16);
-        COGS_VIT_FOLD=0 in the environment turns it off for A/B runs"""
-        import os
+        False keeps LayerNorm as its own kernel (A/B runs: bench.py --no-ln-fold)"""
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.attn_mode = attn_mode
         self.handle = get_handle(self.device)
-        if fold_ln is None and os.environ.get("COGS_VIT_FOLD") == "0":
-            fold_ln = False
         self.packed = PackedVit(state, cfg, dtype, self.device, fold_ln=fold_ln)
         self._activate()
 

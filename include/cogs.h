@@ -75,6 +75,15 @@ cogs_status cogs_profile_begin(cogs_handle h);
  * (a GEMM that the library splits in two counts twice), so ms / launches is comparable with rocprofv3's kernel stats */
 cogs_status cogs_profile_end(cogs_handle h, cogs_stream stream, float* ms_per_class, int* launches_per_class);
 
+/* Diagnostics. The library reads NOTHING from the environment: its A/B switches (which kernel body a shape gets, timing-
+ * only modes, prints) live in one table whose defaults are the shipped behaviour (cogstream_amd/csrc/debug.h lists them;
+ * cogs_debug_list() returns the same text: "name = default: meaning" per line). bench.py --debug, tools/ and the
+ * bit-identity tests flip a switch by name, run, and flip it back inside one process. Process-wide and unsynchronised:
+ * set between calls. Unknown names return COGS_E_INVALID. cogs_debug_get also reports "gemm_last_body". */
+cogs_status cogs_debug_set(const char* name, int64_t value);
+cogs_status cogs_debug_get(const char* name, int64_t* value);
+const char* cogs_debug_list(void);
+
 /* ------------------------------------------------------------------ operator level ---- */
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T). nn.Linear / Conv2d(k=s=14) replacement

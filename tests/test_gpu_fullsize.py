@@ -1,0 +1,248 @@
+"""Direct evidence at PRODUCTION size: the kernels that run the timed step, at the shapes of the timed step, against a
+plain torch fp32 restatement of the same op -- not against another build of themselves and not through a chain of
+smaller cases (round-4 review, "What's weak" 1). The dispatch is asked which body ran (cogs_debug_get), so a shape that
+silently fell back to another kernel fails the test instead of passing on the wrong evidence.
+
+    * gemm_tn_pp64_kernel<EPI> for the four fused ViT epilogues (1027 = bias + residual + row statistics: out-proj / fc2;
+      2053 = LayerNorm fold + rotary: QKV; 2057 = LayerNorm fold + GELU: fc1) and the Qwen2 SwiGLU epilogue, M = 14 824
+      rows (a quarter of the cfg2 clip + a ragged last row block);
+    * attn_prefill_dma_kernel at the cfg2 prompt length (15 395 tokens, 28 / 4 heads) and in the 19-sequence var-len form
+      of the event-summary pass, on 128 sampled query rows each.
+bf16 storage => ~2^-8 relative per rounding; the bounds are the ones the small-shape tests of test_gpu_ops.py use."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+M_FULL = 14824          # 57 whole 256-row blocks + 232 rows
+LOG2E = 1.4426950408889634
+
+
+def _cpu_threads():
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, n)))
+
+
+@pytest.fixture(scope="module")
+def xin():
+    g = torch.Generator().manual_seed(20250824)
+    return (torch.randn(M_FULL, 1152, generator=g) * 0.7 + 0.1).bfloat16()
+
+
+def _whole_line(L):
+    """the whole-line ping-pong kernel computed (all of, or the round-aligned bulk of) the last GEMM"""
+    body = L.debug_get("gemm_last_body")
+    assert body in (4, 5), f"expected gemm_tn_pp64_kernel, the dispatch took body {body}"
+    return body
+
+
+@pytest.mark.parametrize("K", [1152, 4352])
+def test_out_proj_and_fc2_at_production_size_vs_fp32(dev, K):
+    """EPI 1027: x <- A W^T + b + x, plus the (sum, sum of squares) partials of the STORED rows per 64 columns
+    (model/modeling_videollama3_encoder.py:275,373,388-391). K = 1152: out-proj, K = 4352: fc2 (padded intermediate)."""
+    from cogstream_amd import _lib as L
+    from cogstream_amd import ops
+    _cpu_threads()
+    g = torch.Generator().manual_seed(K)
+    H = 1152
+    a = (torch.randn(M_FULL, K, generator=g) * 0.5).bfloat16()
+    w = (torch.randn(H, K, generator=g) / math.sqrt(K)).bfloat16()
+    b = torch.randn(H, generator=g).bfloat16()
+    r = (torch.randn(M_FULL, H, generator=g) * 2 + 0.3).bfloat16()
+    ref = a.float() @ w.float().t() + b.float() + r.float()
+    part = torch.zeros(M_FULL, H // 64, 2, device=dev)
+    out = ops.gemm(a.to(dev), w.to(dev), b.to(dev), residual=r.to(dev), row_stats=part)
+    _whole_line(L)
+    assert rel_err(out.float(), ref) < 1.2e-2
+    # per row: every row block of the ragged grid was written (a skipped tile would leave the allocator's bytes)
+    err_rows = (out.float().cpu() - ref).abs().amax(1) / ref.abs().amax(1)
+    assert float(err_rows.max()) < 2e-2, int(err_rows.argmax())
+    xs = out.float().cpu()
+    want = torch.stack([xs.view(M_FULL, H // 64, 64).sum(-1), (xs ** 2).view(M_FULL, H // 64, 64).sum(-1)], -1)
+    assert rel_err(part, want) < 1e-5
+
+
+def test_qkv_ln_fold_rope_at_production_size_vs_fp32(dev, xin):
+    """EPI 2053: q, k, v = LN(x) W^T + b with the rotary rotation on q, k -- what the encoder's QKV GEMM computes
+    (model/modeling_videollama3_encoder.py:246-248,161-170,382-384), LayerNorm folded (W * gamma centred and zero-sum, rstd
+    per row in the epilogue), 2-D rotary factors from the interleaved per-row table."""
+    from cogstream_amd import _lib as L
+    from cogstream_amd import ops
+    from cogstream_amd.weights import fold_layernorm
+    _cpu_threads()
+    g = torch.Generator().manual_seed(7)
+    H, hd, heads, eps = 1152, 72, 16, 1e-6
+    N = 3 * H
+    w = (torch.randn(N, H, generator=g) / 30).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    gamma, beta = (1 + 0.3 * torch.randn(H, generator=g)).bfloat16(), (0.2 * torch.randn(H, generator=g)).bfloat16()
+    nf = hd // 4
+    hpos = torch.randint(0, 22, (M_FULL,), generator=g)
+    wpos = torch.randint(0, 42, (M_FULL,), generator=g)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(nf, dtype=torch.float32) / nf))
+    ang = torch.cat([hpos[:, None].float() * inv_freq, wpos[:, None].float() * inv_freq], 1)          # [M, hd/2]
+    # reference: LayerNorm, linear, rotate_half on the q and k heads (fp32)
+    x = xin.float()
+    y = (F.layer_norm(x, (H,), gamma.float(), beta.float(), eps) @ w.float().t() + b.float()).view(M_FULL, 3 * heads, hd)
+    cos = torch.cat([ang.cos(), ang.cos()], -1)[:, None, :]
+    sin = torch.cat([ang.sin(), ang.sin()], -1)[:, None, :]
+    rot = torch.cat([-y[..., hd // 2:], y[..., :hd // 2]], -1)
+    ref = y.clone()
+    ref[:, :2 * heads] = (y * cos + rot * sin)[:, :2 * heads]
+    # the library's weight layout: rotary pair (d, d + hd/2) of every q / k head on adjacent output columns
+    perm = torch.arange(hd).view(2, hd // 2).t().reshape(-1)
+    wp, bp = w.view(3 * heads, hd, H).clone(), b.view(3 * heads, hd).clone()
+    wp[:2 * heads] = wp[:2 * heads][:, perm]
+    bp[:2 * heads] = bp[:2 * heads][:, perm]
+    ref[:, :2 * heads] = ref[:, :2 * heads][:, :, perm]
+    wf, _, col_c = fold_layernorm(wp.reshape(N, H).contiguous(), bp.reshape(N).contiguous(), gamma, beta)
+    # row statistics exactly as the producing GEMM leaves them: from the stored bf16 rows
+    mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    ab = torch.stack([rstd, -rstd * mean], 1).float().to(dev)
+    table = torch.stack([ang.cos(), ang.sin()], -1).contiguous().to(dev)
+    out = ops.gemm(xin.to(dev), wf.to(dev), None, ln_ab=ab, col_c=col_c.to(dev), rope_cos=table, rope_sin=None,
+                   rope_cols=2 * H, head_dim=hd)
+    assert _whole_line(L) == 4
+    got = out.float().cpu().view(M_FULL, 3 * heads, hd)
+    assert rel_err(got, ref) < 1.5e-2
+    for name, sl in (("q", slice(0, heads)), ("k", slice(heads, 2 * heads)), ("v", slice(2 * heads, 3 * heads))):
+        e = (got[:, sl] - ref[:, sl]).abs().amax((1, 2)) / ref[:, sl].abs().amax((1, 2))
+        assert float(e.max()) < 2.5e-2, (name, int(e.argmax()), float(e.max()))
+
+
+def test_fc1_ln_fold_gelu_at_production_size_vs_fp32(dev, xin):
+    """EPI 2057: gelu_tanh(LN(x) W1^T + b1) (model/modeling_videollama3_encoder.py:369-372,385-386), N padded to 4352"""
+    from cogstream_amd import _lib as L
+    from cogstream_amd import ops
+    from cogstream_amd.weights import fold_layernorm
+    _cpu_threads()
+    g = torch.Generator().manual_seed(9)
+    H, N, eps = 1152, 4352, 1e-6
+    w = (torch.randn(N, H, generator=g) / 30).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    gamma, beta = (1 + 0.3 * torch.randn(H, generator=g)).bfloat16(), (0.2 * torch.randn(H, generator=g)).bfloat16()
+    x = xin.float()
+    ref = F.gelu(F.layer_norm(x, (H,), gamma.float(), beta.float(), eps) @ w.float().t() + b.float(), approximate="tanh")
+    wf, _, col_c = fold_layernorm(w, b, gamma, beta)
+    mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    ab = torch.stack([rstd, -rstd * mean], 1).float().to(dev)
+    out = ops.gemm(xin.to(dev), wf.to(dev), None, act=L.ACT_GELU_TANH, ln_ab=ab, col_c=col_c.to(dev))
+    assert _whole_line(L) == 4
+    assert rel_err(out.float(), ref) < 1.5e-2
+    err_rows = (out.float().cpu() - ref).abs().amax(1) / ref.abs().amax(1)
+    assert float(err_rows.max()) < 2.5e-2, int(err_rows.argmax())
+
+
+def test_qwen2_gate_up_swiglu_at_production_size_vs_fp32(dev):
+    """EPI_SWIGLU at the Qwen2-7B width (hidden 3584, intermediate 18944; transformers' Qwen2MLP: silu(gate) * up),
+    M = 14 824 prompt rows; the fp32 reference is taken on 384 sampled rows (first / last row blocks + random ones)."""
+    from cogstream_amd import _lib as L
+    from cogstream_amd import ops
+    _cpu_threads()
+    g = torch.Generator(device=dev).manual_seed(13)
+    H, I = 3584, 18944
+    x = (torch.randn(M_FULL, H, generator=g, device=dev) * 0.5).bfloat16()
+    gu = (torch.randn(2 * I, H, generator=g, device=dev) / math.sqrt(H)).bfloat16()      # rows (gate_i, up_i) interleaved
+    out = ops.gemm(x, gu, act=L.ACT_SWIGLU)
+    assert _whole_line(L) == 4 and out.shape == (M_FULL, I)
+    rows = torch.cat([torch.arange(0, 64), torch.arange(M_FULL - 64, M_FULL),
+                      torch.randint(64, M_FULL - 64, (256,), generator=torch.Generator().manual_seed(1))])
+    xs, wc = x[rows.to(dev)].float().cpu(), gu.float().cpu()
+    ref = F.silu(xs @ wc[0::2].t()) * (xs @ wc[1::2].t())
+    got = out[rows.to(dev)].float().cpu()
+    assert rel_err(got, ref) < 1.5e-2
+    err_rows = (got - ref).abs().amax(1) / ref.abs().amax(1)
+    assert float(err_rows.max()) < 2.5e-2, int(rows[err_rows.argmax()])
+    assert torch.isfinite(out.float()).all()
+
+
+def _causal_rows_ref(q, k, v, rows, seg_start, hq, hkv, hd):
+    """fp32 softmax attention of the sampled query rows: row i sees keys seg_start[i] .. i (scores already in log2 units)"""
+    out = torch.empty(len(rows), hq * hd)
+    kf = k.float().view(-1, hkv, hd)
+    vf = v.float().view(-1, hkv, hd)
+    for n, i in enumerate(rows.tolist()):
+        lo = int(seg_start[n])
+        qi = q[i].float().view(hkv, hq // hkv, hd)                       # query heads grouped by their kv head
+        s = torch.einsum("gjd,tgd->gjt", qi, kf[lo:i + 1]) * math.log(2.0)
+        p = torch.softmax(s, -1)
+        out[n] = torch.einsum("gjt,tgd->gjd", p, vf[lo:i + 1]).reshape(-1)
+    return out
+
+
+def _sample_rows(S, bounds, n, seed):
+    """rows around every seam of the kernel's control flow + random ones: sequence starts and ends, 128-row query blocks,
+    64-key tiles"""
+    g = torch.Generator().manual_seed(seed)
+    fixed = set()
+    for b in bounds:
+        for d in (-1, 0, 1, 63, 64, 127, 128):
+            if 0 <= b + d < S:
+                fixed.add(b + d)
+    fixed = sorted(fixed)
+    if len(fixed) > n // 2:                       # too many seams: a random half-budget of them
+        pick = torch.randperm(len(fixed), generator=g)[: n // 2].tolist()
+        fixed = [fixed[j] for j in pick]
+    fixed = sorted(set(fixed) | {0, S - 1, S - 2})
+    rnd = torch.randint(0, S, (max(0, n - len(fixed)),), generator=g).tolist()
+    return torch.tensor(sorted(set(fixed) | set(rnd)))
+
+
+def test_prompt_attention_at_the_cfg2_prompt_length_vs_fp32(dev):
+    """attn_prefill_dma_kernel on the answer prompt of BASELINE configs[1]: 15 395 tokens, 28 query / 4 key-value heads of
+    128, causal, Q pre-scaled by scale * log2(e) (the Qwen2 prompt pass behind model/cogreasoner_chat.py:802-807)."""
+    from cogstream_amd import _lib as L
+    from cogstream_amd import ops
+    _cpu_threads()
+    S, hq, hkv, hd = 15395, 28, 4, 128
+    g = torch.Generator().manual_seed(S)
+    q = (torch.randn(S, hq * hd, generator=g) * (LOG2E / math.sqrt(hd))).bfloat16()
+    k = torch.randn(S, hkv * hd, generator=g).bfloat16()
+    v = torch.randn(S, hkv * hd, generator=g).bfloat16()
+    k[S // 3] *= 3.0                                                     # a dominant key: the running maximum moves late
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True)
+    assert L.debug_get("attn_last_kernel") == 5
+    rows = _sample_rows(S, [0, S // 3, 8192, S], 128, 1)
+    ref = _causal_rows_ref(q, k, v, rows, torch.zeros(len(rows)), hq, hkv, hd)
+    got = out[rows.to(dev)].float().cpu()
+    assert torch.isfinite(out.float()).all()
+    err = (got - ref).abs().view(len(rows), hq, hd).amax(2) / ref.abs().view(len(rows), hq, hd).amax(2).clamp_min(1e-3)
+    assert float(err.max()) < 2e-2, (float(err.max()), int(rows[int(err.argmax()) // hq]))
+    assert rel_err(got, ref) < 1.5e-2
+
+
+def test_prompt_attention_in_the_19_sequence_event_form_vs_fp32(dev):
+    """the same kernel in the var-len form of the event-summary pass (select_events_based_on_summary,
+    model/cogreasoner_chat.py:303-322: K = 18 event prompts + the question as ONE forward): 19 sequences back to back,
+    causal attention restarting at every sequence; lengths of the cfg3 pass (about 900 tokens per event prompt, ragged)."""
+    from cogstream_amd import _lib as L
+    from cogstream_amd import ops
+    _cpu_threads()
+    hq, hkv, hd = 28, 4, 128
+    lens = [974, 911, 850, 1023, 767, 1025, 896, 129, 900, 64, 1, 933, 127, 1200, 880, 970, 905, 860, 31]
+    assert len(lens) == 19
+    S = sum(lens)
+    g = torch.Generator().manual_seed(S)
+    q = (torch.randn(S, hq * hd, generator=g) * (LOG2E / math.sqrt(hd))).bfloat16()
+    k = torch.randn(S, hkv * hd, generator=g).bfloat16()
+    v = torch.randn(S, hkv * hd, generator=g).bfloat16()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True,
+                        cu_seqlens=cu.to(dev), max_seqlen=max(lens))
+    assert L.debug_get("attn_last_kernel") == 5
+    rows = _sample_rows(S, cu.tolist(), 128, 2)
+    seg = torch.bucketize(rows, cu[1:].long(), right=True)
+    ref = _causal_rows_ref(q, k, v, rows, cu.long()[seg], hq, hkv, hd)
+    got = out[rows.to(dev)].float().cpu()
+    assert torch.isfinite(out.float()).all()
+    err = (got - ref).abs().view(len(rows), hq, hd).amax(2) / ref.abs().view(len(rows), hq, hd).amax(2).clamp_min(1e-3)
+    assert float(err.max()) < 2e-2, (float(err.max()), int(rows[int(err.argmax()) // hq]))
+    assert rel_err(got, ref) < 1.5e-2

@@ -558,28 +558,36 @@ def test_pair_epilogue_and_relaxed_vmcnt_equal_the_generic_build_bit_for_bit(dev
             assert torch.equal(a, b), (name, rep, float((a.float() - b.float()).abs().max()))
 
 
-def test_whole_line_gemm_equals_the_k_tile_gemm_bit_for_bit(dev, tmp_path, monkeypatch):
+def test_whole_line_gemm_equals_the_k_tile_gemm_bit_for_bit(dev):
     """gemm_tn_pp64_kernel (round 4: 64-wide slabs of whole 128-byte lines in a five-unit ring, three kinds of slab, the
     two wave groups' epilogues in one interval) must produce the bits of gemm_tn_pp_kernel (32-wide K-tiles): same tile,
-    same MFMA order, same epilogues. The second kernel is reached through a private copy of the library that reads
-    COGS_GEMM_PP64=0 when it initialises. Shapes: the cfg2 ViT GEMMs at a quarter of the clip (several rounds of the
-    persistent grid, ragged last row block), a frame-sharded share (few tiles), the Qwen2 gate/up and down projections
-    at 2 100 rows (SwiGLU epilogue; K = 18 944: 296 slabs per tile)."""
-    import ctypes as C
-    import shutil
+    same MFMA order, same epilogues. The second kernel is reached through the debug switch gemm_pp64 = 0 (the dispatch
+    is asked which body ran). Shapes: the cfg2 ViT GEMMs at a quarter of the clip (several rounds of the persistent grid,
+    ragged last row block), a frame-sharded share (few tiles), the Qwen2 gate/up and down projections at 2 100 rows
+    (SwiGLU epilogue; K = 18 944: 296 slabs per tile)."""
     from cogstream_amd import _lib as L2
     ops = _ops()
     g = torch.Generator(device=dev).manual_seed(11)
     rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).bfloat16()
-    ops.gemm(rnd(1024, 128), rnd(256, 128))                       # the shipped library has read its environment
-    torch.cuda.synchronize()
-    private = tmp_path / "libcogs_hip_ktile.so"
-    shutil.copy(L2.LIB_PATH, private)
-    monkeypatch.setenv("COGS_GEMM_PP64", "0")
-    alt = C.CDLL(str(private))
-    ops.gemm(rnd(1024, 128), rnd(256, 128), lib=alt)              # ... and the private copy its own
-    torch.cuda.synchronize()
-    monkeypatch.delenv("COGS_GEMM_PP64")
+
+    class _KTile:
+        """stands in for the second library of the round-4 form of this test: gemm(..., lib=alt) = the K-tile body"""
+    alt = _KTile()
+    _gemm = ops.gemm
+
+    def gemm_ab(**kw):
+        if kw.pop("lib", None) is None:
+            out = _gemm(**kw)
+            assert L2.debug_get("gemm_last_body") in (2, 4, 5), L2.debug_get("gemm_last_body")
+            return out
+        with L2.debug_switch("gemm_pp64", 0):
+            out = _gemm(**kw)
+            assert L2.debug_get("gemm_last_body") in (2, 3, 5), L2.debug_get("gemm_last_body")
+        return out
+
+    class _Ops:
+        gemm = staticmethod(gemm_ab)
+    ops = _Ops()
     hd, H, I = 72, 1152, 4352
     for M in (59136 // 4 + 40, 6400):
         x, big = rnd(M, H), rnd(M, I)
@@ -612,27 +620,25 @@ def test_whole_line_gemm_equals_the_k_tile_gemm_bit_for_bit(dev, tmp_path, monke
         assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
 
 
-def test_ping_pong_prompt_attention_equals_the_shipped_kernel_bit_for_bit(dev, tmp_path, monkeypatch):
-    """attn_prefill_pp_kernel (round 4, off by default: COGS_ATTN_PREFILL_PP=1) runs the arithmetic of
+def test_ping_pong_prompt_attention_equals_the_shipped_kernel_bit_for_bit(dev):
+    """attn_prefill_pp_kernel (round 4, off by default: debug switch attn_prefill_pp = 1) runs the arithmetic of
     attn_prefill_dma_kernel in a different schedule (256 query rows per workgroup, two wave groups half a tile apart,
     the PV product of a tile one phase late, no skipped MFMAs on masked tiles): the outputs must be the same bits.
     Whole prompt, ragged lengths (one group of the last block idle / partly filled), prefix-KV continuation (q_pos0)."""
-    import ctypes as C
-    import shutil
     from cogstream_amd import _lib as L2
-    ops = _ops()
+    ops0 = _ops()
     g = torch.Generator(device=dev).manual_seed(3)
     hq, hkv, hd = 28, 4, 128
     mk = lambda n, h: (torch.randn(n, h * hd, generator=g, device=dev) * 0.5).bfloat16()
-    ops.attention(mk(300, hq), mk(300, hkv), mk(300, hkv), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True)
-    torch.cuda.synchronize()                                      # the shipped library has read its environment
-    private = tmp_path / "libcogs_hip_pp.so"
-    shutil.copy(L2.LIB_PATH, private)
-    monkeypatch.setenv("COGS_ATTN_PREFILL_PP", "1")
-    alt = C.CDLL(str(private))
-    ops.attention(mk(300, hq), mk(300, hkv), mk(300, hkv), hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True, lib=alt)
-    torch.cuda.synchronize()
-    monkeypatch.delenv("COGS_ATTN_PREFILL_PP")
+    alt = object()
+
+    class ops:
+        @staticmethod
+        def attention(*a, lib=None, **kw):
+            if lib is None:
+                return ops0.attention(*a, **kw)
+            with L2.debug_switch("attn_prefill_pp", 1):
+                return ops0.attention(*a, **kw)
     for S, pos0 in ((4096, 0), (2100, 0), (2433, 0), (300, 0), (1000, 1500)):
         q, kk, v = mk(S, hq), mk(S + pos0, hkv), mk(S + pos0, hkv)
         a = ops.attention(q, kk, v, hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True, q_pos0=pos0)

@@ -13,7 +13,7 @@ done
 for rep in 1 2; do
   i=0
   for v in "$@"; do
-    echo "== [$v]"; COGS_ATTN_VIT=2 timeout -k 10 60 $O/m_$i 64 924; COGS_ATTN_VIT=2 timeout -k 10 60 $O/m_$i 16 3696
+    echo "== [$v]"; timeout -k 10 60 $O/m_$i 64 924; timeout -k 10 60 $O/m_$i 16 3696
     i=$((i+1))
   done
 done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the loader-wave GEMM prototype (tools/experiments/gemm_lw.hip, cogs_x_gemm_lw) against the shipped cogs_gemm on the four
 ViT shapes of cfg2: python tools/experiments/gemm_lw_ab.py [M]. Correctness first (against torch fp32 matmul of the bf16 operands,
-ragged M / N), then back-to-back timings. COGS_GEMM_NOSTORE=1 in the environment puts cogs_gemm in its K-loop-only
+ragged M / N), then back-to-back timings. --nostore on the command line puts cogs_gemm in its K-loop-only
 diagnostic mode; the prototype's own nostore flag is timed beside it."""
 import ctypes as C
 import os
@@ -59,7 +59,10 @@ for (M, N, K) in ((1000, 1152, 1152), (2048, 3456, 1152), (777, 200, 64), (3000,
     assert err < 1e-2
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 59136
-nostore_env = os.environ.get("COGS_GEMM_NOSTORE") is not None
+nostore_env = "--nostore" in sys.argv
+if nostore_env:
+    from cogstream_amd import _lib as _L
+    _L.debug_set("gemm_nostore", 1)
 for name, N, K in (("o", 1152, 1152), ("fc2", 1152, 4352), ("qkv", 3456, 1152), ("fc1", 4352, 1152)):
     a = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
     w = ((torch.rand(N, K, device=dev) * 2 - 1) * 0.05).bfloat16()

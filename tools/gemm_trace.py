@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""Per-tile cycle stamps of the ping-pong GEMM (COGS_GEMM_TRACE=1): K-loop / epilogue cycles of workgroup 0."""
+"""Per-tile cycle stamps of the ping-pong GEMM (debug switch gemm_trace): K-loop / epilogue cycles of workgroup 0."""
 import os
 import sys
 
-os.environ.setdefault("COGS_GEMM_TRACE", "1")
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogstream_amd import _lib as L  # noqa: E402
 from cogstream_amd import ops  # noqa: E402
+
+L.debug_from_argv(sys.argv)
+L.debug_set("gemm_trace", 1)
+L.debug_set("gemm_split", 0)
 
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "vit"
@@ -31,7 +34,6 @@ for name, N, K, kw in shapes:
         args["act"] = kw["act"]
     if kw.get("rope"):
         args.update(rope_cos=torch.rand(M, 36, 2, device=dev), rope_sin=None, rope_cols=2304, head_dim=72)
-    os.environ["COGS_GEMM_NOSPLIT"] = "1"
     print("==", name, file=sys.stderr)
     for _ in range(2):
         ops.gemm(a, w, **args)

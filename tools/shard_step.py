@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """One rank's share of a frame-sharded encode, alone on one GPU (for rocprofv3 --kernel-trace --stats):
-    shard_step.py <frames> <gh> <gw> [steps]      e.g. 32 10 20 (cfg3 / 8 ranks), 8 22 42 (cfg2 / 8 ranks)"""
+    shard_step.py <frames> <gh> <gw> [steps] [--debug name=value,...]     e.g. 32 10 20 (cfg3 / 8 ranks), 8 22 42 (cfg2 / 8 ranks)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cogstream_amd import _lib as L
 from cogstream_amd.vision import Projector, VisionEncoder
 from cogstream_amd.weights import VisionConfig, random_proj_state, random_vit_state
 
+L.debug_from_argv(sys.argv)       # e.g. --debug gemm_pingpong=0
 T, gh, gw = (int(v) for v in sys.argv[1:4])
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 dev = torch.device("cuda:0")
