@@ -52,6 +52,8 @@ class GemmDesc(C.Structure):
         ("row_stats", c_void_p),
         ("ln_ab", c_void_p),
         ("col_c", c_void_p),
+        ("hm_rows", c_int64),
+        ("hm_cols", c_int),
     ]
 
 
@@ -69,6 +71,7 @@ class AttnDesc(C.Structure):
         ("force_rowwise", c_int),
         ("nsplit", c_int), ("ws", c_void_p), ("ws_bytes", c_size_t),
         ("q_prescaled", c_int),
+        ("head_stride", c_int64),
     ]
 
 

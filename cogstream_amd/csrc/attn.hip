@@ -1302,6 +1302,7 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
     if (a.dtype == COGS_DT_BF16 && !a.force_rowwise && a.head_dim == 72 && a.q_prescaled && a.cu_seqlens && !a.row_lo &&
         !a.causal && a.nsplit <= 1 && a.hq == a.hkv && a.ldo % 8 == 0 && !env_old_vit)
         return cogs_k_attention_vit(st, a);
+    if (a.head_stride > 0) return COGS_E_UNSUPPORTED;      // head-major Q / K / V: the encoder's production kernel only
     if (a.dtype == COGS_DT_BF16 && !a.force_rowwise && (a.head_dim == 72 || a.head_dim == 128)) {
         if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) return COGS_E_INVALID;
         const int max_len = a.cu_seqlens ? a.max_seqlen : a.q_len;

@@ -38,6 +38,9 @@ struct VitAttnArgs {
     const int* cu;             // [nseg + 1]
     int nseg, heads, nqb;      // grid = nseg * heads * nqb workgroups (nqb = 128-row query blocks of the longest segment)
     int early_prefetch;        // pipe kernel prologue: tiles 1 and 2 issued before (1) / behind (0) the first wait
+    long head_stride;          // elements from head h to head h + 1 of Q / K / V: HD for the token-major layout (ld* = row stride of
+                               // the fused qkv buffer), rows * HD for the head-major one (ld* = HD: a head's rows back to back, so a
+                               // key tile is ONE contiguous run of 64 x 144 bytes and every 1 KiB LDS-DMA piece is whole lines)
     int uniform_len;           // > 0: every segment has this many rows and segment s starts at row s * uniform_len (one video:
                                // all frames alike) -- the bounds are then arithmetic on kernel arguments instead of two
                                // dependent scalar loads at the head of every workgroup (700-1 700 cycles of its 39 000)
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
     for (int s = 0; s < KS; ++s) {
         const int k = 16 * s + 8 * h;
         qf[s] = u32x4{0, 0, 0, 0};
-        if (qok && k < HD) qf[s] = *reinterpret_cast<const u32x4*>(p.Q + (long)qrow * p.ldq + head * HD + k);
+        if (qok && k < HD) qf[s] = *reinterpret_cast<const u32x4*>(p.Q + (long)qrow * p.ldq + head * p.head_stride + k);
     }
 
     // staging: thread -> chunk column c = tid % CH, rows tid / CH + RSTEP * i (i < PER): every slot's offsets are the
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
     constexpr int PER = (64 + RSTEP - 1) / RSTEP;            // 3
     const int st_row0 = tid < RSTEP * CH ? tid / CH : 1 << 20;
     const int st_c = tid % CH;
-    const int g_off_k0 = st_row0 * (int)p.ldk + head * HD + st_c * 8;
-    const int g_off_v0 = st_row0 * (int)p.ldv + head * HD + st_c * 8;
+    const long g_off_k0 = (long)st_row0 * p.ldk + head * p.head_stride + st_c * 8;
+    const long g_off_v0 = (long)st_row0 * p.ldv + head * p.head_stride + st_c * 8;
     const int l_off_k0 = st_row0 * KRS + st_c * 16;
     const int l_off_v0 = KT + st_row0 * VRS + st_c * 16;
     u32x4 kreg[PER], vreg[PER];
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     for (int s = 0; s < KS; ++s) {
         const int k = 16 * s + 8 * h;
         qf[s] = u32x4{0, 0, 0, 0};
-        if (qok && k < HD) qf[s] = *reinterpret_cast<const u32x4*>(p.Q + (long)qrow * p.ldq + head * HD + k);
+        if (qok && k < HD) qf[s] = *reinterpret_cast<const u32x4*>(p.Q + (long)qrow * p.ldq + head * p.head_stride + k);
     }
 
     // DMA pieces: piece j (0..8) of a matrix covers chunks 64j..64j+63 of the tile image (chunk c = row c / 9, 16-byte
@@ -459,8 +462,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     for (int i = 0; i < 3; ++i) {
         const int c = (i < 2 ? wid + 4 * i : 8) * 64 + lane;
         pc_row[i] = c / CH;
-        pc_off[i] = (pc_row[i] * (int)p.ldk + head * HD + (c % CH) * 8) * 2;   // bytes; ldk == ldv (checked by the launcher)
-    }
+        pc_off[i] = (pc_row[i] * (int)p.ldk + (c % CH) * 8) * 2;   // bytes; ldk == ldv (checked by the launcher). Head-major
+    }                                                              // (ldk = HD): = 16 c, the piece is one contiguous KiB
     // The DMA is issued from inline assembly: hipcc's wait insertion treats a `global_load_lds` it can see as a pending
     // LDS store and puts `s_waitcnt vmcnt(0)` in front of the first ds_read_b64_tr_b16 of every tile (the transposing
     // read carries no memory operand to disambiguate), which would drain the three-tile prefetch every iteration. Hidden
@@ -480,8 +483,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     auto issue_tile = [&](int t) {
         const int kbase = qs + t * 64;
         const int valid = qe - kbase;                            // >= 1
-        const bf16_t* kb = uniform_ptr(p.K + (long)kbase * p.ldk);
-        const bf16_t* vb = uniform_ptr(p.V + (long)kbase * p.ldv);
+        const bf16_t* kb = uniform_ptr(p.K + (long)kbase * p.ldk + head * p.head_stride);
+        const bf16_t* vb = uniform_ptr(p.V + (long)kbase * p.ldv + head * p.head_stride);
         const unsigned st = __builtin_amdgcn_readfirstlane(smem_lds + (t & (NS - 1)) * STAGE);
         int off[3];
 #pragma unroll
@@ -778,6 +781,8 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo;
     p.cu = a.cu_seqlens;
     p.nseg = a.nseg; p.heads = a.hq; p.nqb = (a.max_seqlen + 127) / 128;
+    p.head_stride = a.head_stride > 0 ? a.head_stride : 72;
+    if (a.head_stride > 0 && (a.ldq != 72 || a.ldk != 72 || a.ldv != 72)) return COGS_E_INVALID;
     p.uniform_len = (a.uniform_seqlen > 0 && (long)a.uniform_seqlen * a.nseg == a.q_len && a.uniform_seqlen == a.max_seqlen) ? a.uniform_seqlen : 0;
     if ((long)p.nseg * p.heads * p.nqb > 0x7fffffffL) return COGS_E_INVALID;
     dim3 grid(p.nseg * p.heads * p.nqb);
@@ -785,6 +790,6 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     const int env_early = (int)g_cogs_debug.attn_vit_early;
     p.early_prefetch = env_early;
     if (variant == 1 || a.ldk != a.ldv) { g_cogs_debug.attn_last_kernel = 2; hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p); }
-    else { g_cogs_debug.attn_last_kernel = 3; hipLaunchKernelGGL(attn_vit_pipe_kernel<72>, grid, dim3(256), 0, st, p); }
+    else { g_cogs_debug.attn_last_kernel = a.head_stride > 0 ? 8 : 3; hipLaunchKernelGGL(attn_vit_pipe_kernel<72>, grid, dim3(256), 0, st, p); }
     return COGS_LAUNCH_CHECK();
 }

@@ -133,6 +133,7 @@ CogsGemm to_gemm(const cogs_gemm_desc* d) {
     g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.rope_cols = d->rope_cols; g.head_dim = d->head_dim;
     g.rope_lut = d->rope_lut; g.rope_rowpos = d->rope_rowpos; g.rope_maxpos = d->rope_maxpos;
     g.row_stats = d->row_stats; g.ln_ab = d->ln_ab; g.col_c = d->col_c;
+    g.hm_rows = d->hm_rows; g.hm_cols = d->hm_cols;
     return g;
 }
 
@@ -255,6 +256,7 @@ cogs_status cogs_attention(cogs_stream stream, const cogs_attn_desc* d) {
     a.scale = d->scale; a.causal = d->causal; a.q_pos0 = d->q_pos0; a.force_rowwise = d->force_rowwise;
     a.nsplit = d->nsplit > 1 ? d->nsplit : 1; a.ws = d->ws; a.ws_bytes = d->ws_bytes;
     a.q_prescaled = d->q_prescaled;
+    a.head_stride = d->head_stride;
     return cogs_k_attention((hipStream_t)stream, a);
 }
 
@@ -629,6 +631,12 @@ static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* p
     // before its single rounding (same relative rounding error as rounding q itself) and the softmax needs no
     // per-score multiply. Not in the parity modes (fp32, or the eager-global bias mode).
     const bool prescale_q = dt == COGS_DT_BF16 && attn_mode == COGS_ATTN_BLOCK_DIAG && (hd == 72 || hd == 128);
+    // Round 5: the production path keeps q, k, v HEAD-major between the QKV GEMM and the attention kernel --
+    // [q | k | v][head][row][hd] in the same N x 3H elements -- so that a (frame, head) block of K / V is one contiguous
+    // run and the attention kernel's LDS-DMA pieces are whole 128-byte lines (csrc/gemm_epilogue.h EPI_HM, csrc/attn_vit.hip).
+    // Only that kernel reads the layout; the parity modes (fp32, eager-global) stay token-major.
+    const bool head_major = prescale_q && hd == 72 && g_cogs_debug.gemm_headmajor != 0 && g_cogs_debug.attn_vit != 0 &&
+                            (double)N * H * 2.0 < 4294967296.0;
     for (int l = 0; l < w.layers; ++l) {
         const cogs_vit_layer& L = h->vit_layers[l];
         if (fold) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_ln_finalize(st, stat_part, (int)N, H / 64, H, w.ln_eps, ln_ab)); }
@@ -642,12 +650,17 @@ static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* p
             g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = 2 * H; g.head_dim = hd;
             if (prescale_q) { g.q_scale = scale * 1.4426950408889634f; g.q_cols = H; }
             if (use_lut) { g.rope_lut = lut; g.rope_rowpos = lo; g.rope_maxpos = maxpos; }
+            if (head_major) { g.hm_rows = N; g.hm_cols = H; }
             { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
         }
         {
             CogsAttn a; a.dtype = dt;
             a.Q = qkv; a.K = qkv + (size_t)H * es; a.V = qkv + (size_t)2 * H * es; a.O = att;
             a.ldq = a.ldk = a.ldv = 3 * H; a.ldo = H;
+            if (head_major) {
+                a.K = qkv + (size_t)N * H * es; a.V = qkv + (size_t)2 * N * H * es;
+                a.ldq = a.ldk = a.ldv = hd; a.head_stride = (long)N * hd;
+            }
             a.q_len = (int)N; a.kv_len = (int)N; a.hq = a.hkv = w.heads; a.head_dim = hd; a.scale = scale;
             a.q_prescaled = prescale_q;
             if (attn_mode == COGS_ATTN_REF_EAGER_GLOBAL) { a.row_lo = lo; a.row_hi = hi; a.bias = 1.0f; }

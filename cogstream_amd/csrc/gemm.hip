@@ -1006,6 +1006,8 @@ void dispatch_pp(hipStream_t st, const GemmArgs& p, int grid, int mask) {
         COGS_PP_CASE(EPI_BIAS | EPI_ROPE | EPI_LNFOLD)
         COGS_PP_CASE(EPI_BIAS | EPI_ROPE | EPI_ROPE_LUT | EPI_LNFOLD)
         COGS_PP_CASE(EPI_BIAS | EPI_GELU_TANH | EPI_LNFOLD)
+        COGS_PP_CASE(EPI_BIAS | EPI_ROPE | EPI_HM)
+        COGS_PP_CASE(EPI_BIAS | EPI_ROPE | EPI_LNFOLD | EPI_HM)
         COGS_PP_CASE(EPI_SWIGLU)
         COGS_PP_CASE(EPI_F32OUT)
         COGS_PP_CASE(EPI_NOSTORE)
@@ -1031,6 +1033,8 @@ void dispatch(hipStream_t st, const GemmArgs& p, int grid, int mask, bool big) {
         COGS_EPI_CASE(EPI_BIAS | EPI_LNFOLD)
         COGS_EPI_CASE(EPI_BIAS | EPI_ROPE | EPI_LNFOLD)
         COGS_EPI_CASE(EPI_BIAS | EPI_GELU_TANH | EPI_LNFOLD)
+        COGS_EPI_CASE(EPI_BIAS | EPI_ROPE | EPI_HM)
+        COGS_EPI_CASE(EPI_BIAS | EPI_ROPE | EPI_LNFOLD | EPI_HM)
         COGS_EPI_CASE(EPI_SWIGLU)
         COGS_EPI_CASE(EPI_F32OUT)
         default: if (big) launch_big<T, EPI_GENERIC>(st, p, grid); else launch_small<T, EPI_GENERIC>(st, p, grid); break;
@@ -1049,6 +1053,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
     // the fused-LayerNorm features exist in the specialised MFMA epilogues only: the single-row GEMV and the run-time
     // (EPI_GENERIC) epilogue know neither, and silently dropping them would return un-normalised rows
     if ((g.row_stats || g.ln_ab) && (g.M == 1 || cogs_epi_mask(g) == EPI_GENERIC)) return COGS_E_UNSUPPORTED;
+    if (g.hm_rows > 0 && (g.M == 1 || g.dtype != COGS_DT_BF16)) return COGS_E_UNSUPPORTED;       // head-major output: bf16 MFMA kernels only
     if (g.M == 1) { ++g_gemm_launches; g_cogs_debug.gemm_last_body = 6; return cogs_k_gemv(st, g); }
     if (g.rms_gamma) return COGS_E_UNSUPPORTED;   // fused RMSNorm exists for the single-token GEMV only
     GemmArgs p;
@@ -1141,7 +1146,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
             CogsGemm b = g;
             b.M = g.M - rows_main; b.force_mid_tile = 1;
             b.A = (const char*)g.A + (size_t)rows_main * g.lda * es;
-            b.C = (char*)g.C + (size_t)rows_main * g.ldc * (g.out_f32 ? 4 : es);
+            b.C = (char*)g.C + (size_t)rows_main * (g.hm_rows > 0 ? g.head_dim : g.ldc) * (g.out_f32 ? 4 : es);   // head-major: rows advance by head_dim inside every head block
             if (g.residual) b.residual = (const char*)g.residual + (size_t)rows_main * g.ldr * es;
             if (g.rope_rowpos) b.rope_rowpos = g.rope_rowpos + rows_main;
             if (g.row_stats) b.row_stats = g.row_stats + (size_t)rows_main * (g.N / 64) * 2;

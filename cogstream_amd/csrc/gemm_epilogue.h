@@ -42,6 +42,13 @@
 //                (weights.fold_layernorm) makes the rounded rows sum to zero as well, so there is nothing to neglect.
 #define EPI_ROWSTAT 1024
 #define EPI_LNFOLD 2048
+// Head-major output (round 5; the ViT QKV GEMM): instead of C[m][n] the element of row m, column n goes to
+//   C + ((n / hm_cols) * hm_rows * hm_cols  +  ((n % hm_cols) / hm_hd) * hm_rows * hm_hd  +  m * hm_hd  +  n % hm_hd)
+// i.e. [q | k | v][head][row][head_dim]: every (head, frame) block of K and V is ONE contiguous run of rows, so the
+// attention kernel's 1 KiB LDS-DMA pieces are whole 128-byte lines (54 B/clk per CU against 28 for the 144-byte runs at a
+// 6 912-byte stride of the row-major layout: profiles/r4_ldsdma_rate.txt). 8 consecutive columns that start at a multiple
+// of 8 never leave a head (hm_hd % 8 == 0), so the 16-byte stores of the wide paths stay whole.
+#define EPI_HM 4096
 
 struct EpiArgs {
     char* C; long ldc;          // elements per row
@@ -63,7 +70,19 @@ struct EpiArgs {
     int stat_tiles;             //   = N / 64
     const float* ln_ab;         // EPI_LNFOLD: [M][2] fp32 (rstd, -rstd * mean); the epilogues read rstd only (centred W)
     const float* col_c;         //   [N] fp32 (replaces bias)
+    long hm_rows;               // EPI_HM: rows of the whole output (the head stride is hm_rows * hm_hd elements); 0 = row-major
+    int hm_hd, hm_cols;         //   head_dim and columns per q / k / v block (= heads * head_dim)
 };
+
+// element offset of (row m, column n) in C: row-major, or head-major (see EPI_HM). HM is a compile-time choice in the
+// specialised epilogues (the row-major kernels carry none of this) and a run-time one in the generic epilogue4.
+template <bool HM>
+__device__ __forceinline__ long c_elem(const EpiArgs& p, long m, int n) {
+    if constexpr (!HM) return m * p.ldc + n;
+    const int which = n / p.hm_cols, cw = n - which * p.hm_cols;
+    const int head = cw / p.hm_hd, d = cw - head * p.hm_hd;
+    return ((long)which * p.hm_cols + (long)head * p.hm_hd) * p.hm_rows + m * p.hm_hd + d;
+}
 
 // sum over the four lanes {r, r+16, r+32, r+48} that share a row of a 16x16 accumulator tile, result in all four
 __device__ __forceinline__ float rowgroup_sum(float x) {
@@ -126,7 +145,7 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& p, int m, int n, f32x4 
     if (p.out_f32)
         st4_f<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
     else
-        st4_f<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
+        st4_f<T>(reinterpret_cast<T*>(p.C) + (p.hm_rows ? c_elem<true>(p, m, n) : c_elem<false>(p, m, n)), v);
 }
 
 // raw storage of 4 consecutive elements (converted to fp32 only when used)
@@ -297,7 +316,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
                             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                             const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                             if (m < M && nb + 32 * pr < N)   // N % 32 == 0: a tile pair is entirely inside or outside
-                                *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + nb + 32 * pr + wcol) =
+                                *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + c_elem<(EPI & EPI_HM) != 0>(p, m, nb + 32 * pr + wcol)) =
                                     u32x4{s0[0], s1[0], s0[1], s1[1]};
                         }
                     }
@@ -320,7 +339,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
                             } else if constexpr ((EPI & EPI_F32OUT) != 0) {
                                 st4_f<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v[ni]);
                             } else {
-                                st4_f<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v[ni]);
+                                st4_f<T>(reinterpret_cast<T*>(p.C) + c_elem<(EPI & EPI_HM) != 0>(p, m, n), v[ni]);
                             }
                         }
                     }
@@ -347,9 +366,22 @@ __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int
     typedef bf16_t T;
     const int r = lane & 15, g4 = lane >> 4;
     const int wcol = 16 * (g4 & 1) + 8 * (g4 >> 1);
-    char* const cbase = p.C + ((long)mb * p.ldc + nb) * 2;
-    const unsigned c_lane = ((unsigned)r * (unsigned)p.ldc + (unsigned)wcol) * 2u;
-    const long c_row16 = p.ldc * 32;
+    char* cbase;
+    unsigned c_lane, c_lane1;
+    long c_row16;
+    if constexpr ((EPI & EPI_HM) != 0) {     // see epilogue_pair_fast
+        const int which = nb / p.hm_cols, cw0 = nb - which * p.hm_cols + wcol;
+        cbase = p.C + ((long)which * p.hm_cols * p.hm_rows + (long)mb * p.hm_hd) * 2;
+        const int h0 = cw0 / p.hm_hd, h1 = (cw0 + 32) / p.hm_hd;
+        c_lane = (unsigned)(((long)h0 * p.hm_rows + r) * p.hm_hd + (cw0 - h0 * p.hm_hd)) * 2u;
+        c_lane1 = (unsigned)(((long)h1 * p.hm_rows + r) * p.hm_hd + (cw0 + 32 - h1 * p.hm_hd)) * 2u;
+        c_row16 = (long)p.hm_hd * 32;
+    } else {
+        cbase = p.C + ((long)mb * p.ldc + nb) * 2;
+        c_lane = ((unsigned)r * (unsigned)p.ldc + (unsigned)wcol) * 2u;
+        c_lane1 = 0;                   // row-major: tile pair 1 is 64 bytes further (an immediate in the store)
+        c_row16 = p.ldc * 32;
+    }
     const char* rbase = nullptr;
     unsigned r_lane = 0;
     long r_row16 = 0;
@@ -433,7 +465,8 @@ __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int
                 const unsigned b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
                 const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                *reinterpret_cast<u32x4*>(cbase + mi * c_row16 + c_lane + 64 * pr) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                if constexpr ((EPI & EPI_HM) != 0) *reinterpret_cast<u32x4*>(cbase + mi * c_row16 + (pr ? c_lane1 : c_lane)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                else *reinterpret_cast<u32x4*>(cbase + mi * c_row16 + c_lane + 64 * pr) = u32x4{s0[0], s1[0], s0[1], s1[1]};
             }
         }
     }
@@ -444,8 +477,9 @@ template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_wave(const EpiArgs& p, int mb, int nb, int M, int N, int lane,
                                               f32x4 (&acc)[4][4]) {
     if constexpr (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE | EPI_ROWSTAT | EPI_LNFOLD)) == 0) {
-        bool fast = mb + 64 <= M && nb + 64 <= N && (N & 31) == 0 && (p.ldc & 7) == 0 &&
-                    (reinterpret_cast<unsigned long>(p.C) & 15) == 0;
+        bool fast = mb + 64 <= M && nb + 64 <= N && (N & 31) == 0 && (reinterpret_cast<unsigned long>(p.C) & 15) == 0;
+        if constexpr ((EPI & EPI_HM) != 0) fast = fast && (p.hm_cols & 63) == 0 && (p.hm_hd & 7) == 0;
+        else fast = fast && (p.ldc & 7) == 0;
         if constexpr ((EPI & EPI_RES) != 0) fast = fast && (p.ldr & 7) == 0 && (reinterpret_cast<unsigned long>(p.R) & 15) == 0;
         if constexpr ((EPI & EPI_ROPE) != 0) {
             fast = fast && p.rope_sin == nullptr && p.head_dim >= 64 && (nb + 64 <= p.rope_cols || nb >= p.rope_cols) &&
@@ -479,9 +513,24 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
     else asm volatile("s_nop 8" ::: "memory");
     const int r = lane & 15, g4 = lane >> 4;
     const int wcol = 16 * (g4 & 1) + 8 * (g4 >> 1);
-    char* const cbase = p.C + ((long)mb * p.ldc + nb) * 2;
-    const unsigned c_lane = ((unsigned)r * (unsigned)p.ldc + (unsigned)wcol) * 2u;
-    const long c_row16 = p.ldc * 32;
+    char* cbase;
+    unsigned c_lane, c_lane1;          // byte offsets of this lane's 16 bytes in tile pair 0 / 1 of a row block
+    long c_row16;
+    if constexpr ((EPI & EPI_HM) != 0) {
+        // head-major: the wave tile's 64 columns lie inside ONE of q / k / v (hm_cols % 64 == 0, checked by the caller) and
+        // touch at most two heads; a lane's 8 columns of a tile pair never leave a head. Row blocks advance by 16 rows of hd.
+        const int which = nb / p.hm_cols, cw0 = nb - which * p.hm_cols + wcol;
+        cbase = p.C + ((long)which * p.hm_cols * p.hm_rows + (long)mb * p.hm_hd) * 2;
+        const int h0 = cw0 / p.hm_hd, h1 = (cw0 + 32) / p.hm_hd;
+        c_lane = (unsigned)(((long)h0 * p.hm_rows + r) * p.hm_hd + (cw0 - h0 * p.hm_hd)) * 2u;     // < 2^32: checked on the host
+        c_lane1 = (unsigned)(((long)h1 * p.hm_rows + r) * p.hm_hd + (cw0 + 32 - h1 * p.hm_hd)) * 2u;
+        c_row16 = (long)p.hm_hd * 32;
+    } else {
+        cbase = p.C + ((long)mb * p.ldc + nb) * 2;
+        c_lane = ((unsigned)r * (unsigned)p.ldc + (unsigned)wcol) * 2u;
+        c_lane1 = 0;                   // row-major: tile pair 1 is 64 bytes further (an immediate in the store)
+        c_row16 = p.ldc * 32;
+    }
     const char* rbase = nullptr;
     unsigned r_lane = 0;
     long r_row16 = 0;
@@ -644,7 +693,8 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
 #pragma unroll
         for (int j = 0; j < UPB; ++j) {
             const int u = UPB * b + j, blk = u >> 1, pr = u & 1;
-            *reinterpret_cast<u32x4*>(cbase + blk * c_row16 + c_lane + 64 * pr) = outv[j];
+            if constexpr ((EPI & EPI_HM) != 0) *reinterpret_cast<u32x4*>(cbase + blk * c_row16 + (pr ? c_lane1 : c_lane)) = outv[j];
+            else *reinterpret_cast<u32x4*>(cbase + blk * c_row16 + c_lane + 64 * pr) = outv[j];
         }
         if constexpr ((EPI & EPI_ROWSTAT) != 0) {
             static_assert((EPI & EPI_ROWSTAT) == 0 || UPB == 4, "row statistics are laid out for 4-unit batches");
@@ -683,8 +733,9 @@ __device__ __forceinline__ int epilogue_wave_pair(const EpiArgs& p, int mb, int 
                                                   f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4]) {
 #ifndef COGS_EPI_NOPAIR   // (A/B builds; also the build's fallback when the vmem-count check fails)
     if constexpr (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0) {
-        bool fast = mb + 128 <= M && nb + 64 <= N && (N & 31) == 0 && (p.ldc & 7) == 0 &&
-                    (reinterpret_cast<unsigned long>(p.C) & 15) == 0;
+        bool fast = mb + 128 <= M && nb + 64 <= N && (N & 31) == 0 && (reinterpret_cast<unsigned long>(p.C) & 15) == 0;
+        if constexpr ((EPI & EPI_HM) != 0) fast = fast && (p.hm_cols & 63) == 0 && (p.hm_hd & 7) == 0;
+        else fast = fast && (p.ldc & 7) == 0;
         if constexpr ((EPI & EPI_RES) != 0) fast = fast && (p.ldr & 7) == 0 && (reinterpret_cast<unsigned long>(p.R) & 15) == 0;
         if constexpr ((EPI & EPI_ROPE) != 0) {
             fast = fast && p.rope_sin == nullptr && p.head_dim >= 64 && (nb + 64 <= p.rope_cols || nb >= p.rope_cols) &&
@@ -719,6 +770,15 @@ inline int cogs_fill_epi(const CogsGemm& g, EpiArgs* e) {
     e->rope_rowpos = g.rope_rowpos; e->rope_lut_lds = 0; e->rope_maxpos = g.rope_maxpos;
     e->stat_part = g.row_stats; e->stat_tiles = g.N / 64;
     e->ln_ab = g.ln_ab; e->col_c = g.col_c;
+    e->hm_rows = 0; e->hm_hd = 1; e->hm_cols = 1;
+    if (g.hm_rows > 0) {
+        // head-major output: bf16 q | k | v blocks of whole heads, every column a rotary / plain head column
+        if (g.head_dim <= 0 || g.head_dim % 8 != 0 || g.hm_cols <= 0 || g.hm_cols % g.head_dim != 0 || g.N % g.hm_cols != 0 ||
+            g.out_f32 || g.act != COGS_ACT_NONE || g.residual || g.row_stats || g.hm_rows < g.M ||
+            (double)g.hm_rows * g.hm_cols * 2.0 >= 4294967296.0)          // a lane's offset inside one q / k / v block is 32 bits
+            return COGS_E_INVALID;
+        e->hm_rows = g.hm_rows; e->hm_hd = g.head_dim; e->hm_cols = g.hm_cols;
+    }
     if (g.row_stats && (g.N % 64 != 0 || g.out_f32 || g.act == COGS_ACT_SWIGLU)) return COGS_E_INVALID;
     if (g.ln_ab && (!g.col_c || g.act == COGS_ACT_SWIGLU || g.N % 4 != 0)) return COGS_E_INVALID;
     return COGS_OK;
@@ -736,11 +796,13 @@ inline int cogs_epi_mask(const CogsGemm& g) {
     if (g.act == COGS_ACT_GELU_ERF) m |= EPI_GELU_ERF;
     if (g.act == COGS_ACT_SWIGLU) m |= EPI_SWIGLU;
     if (g.out_f32) m |= EPI_F32OUT;
+    if (g.hm_rows > 0) m |= EPI_HM;
     switch (m) {
         case 0: case EPI_BIAS: case EPI_RES: case EPI_BIAS | EPI_RES: case EPI_BIAS | EPI_ROPE:
         case EPI_BIAS | EPI_GELU_TANH: case EPI_BIAS | EPI_GELU_ERF: case EPI_SWIGLU: case EPI_F32OUT:
         case EPI_BIAS | EPI_ROWSTAT: case EPI_BIAS | EPI_RES | EPI_ROWSTAT:
         case EPI_BIAS | EPI_ROPE | EPI_LNFOLD: case EPI_BIAS | EPI_GELU_TANH | EPI_LNFOLD: case EPI_BIAS | EPI_LNFOLD:
+        case EPI_BIAS | EPI_ROPE | EPI_HM: case EPI_BIAS | EPI_ROPE | EPI_LNFOLD | EPI_HM:
             return m;
         default:
             return EPI_GENERIC;

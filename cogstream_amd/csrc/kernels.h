@@ -40,6 +40,9 @@ struct CogsGemm {
     // LayerNorm fused around the GEMM (gemm_epilogue.h EPI_ROWSTAT / EPI_LNFOLD; bf16 kernels):
     float* row_stats = nullptr;              // != null: also write per-row partial (sum, sum of squares) of the outputs,
                                              //   [M][N/64][2] fp32 (N % 64 == 0)
+    // head-major output (gemm_epilogue.h EPI_HM; bf16, rotary epilogues): hm_rows > 0 = rows of the whole output buffer, C is
+    // [N / hm_cols][hm_cols / head_dim][hm_rows][head_dim] instead of [M][N] (ldc ignored); M <= hm_rows rows are written
+    long hm_rows = 0; int hm_cols = 0;
     const float* ln_ab = nullptr;            // != null: y = ln_ab[r][0] * acc + col_c[n] instead of acc + bias. W = rows of
     const float* col_c = nullptr;            //   W0*diag(gamma) made ZERO-SUM over k, col_c = bias + W0.beta; bias must be null
                                              //   (include/cogs.h, cogs_gemm_desc.ln_ab, has the contract)
@@ -72,6 +75,7 @@ struct CogsAttn {
     size_t ws_bytes = 0;
     int q_prescaled = 0;              // Q already multiplied by scale*log2(e) (bf16 MFMA kernels only; no bias mode)
     int uniform_seqlen = 0;           // internal hint: > 0 = every cu_seqlens segment has exactly this many rows, in order
+    long head_stride = 0;             // > 0: head-major Q / K / V (include/cogs.h cogs_attn_desc.head_stride); ViT kernel only
 };
 int cogs_k_attention_vit(hipStream_t st, const struct CogsAttn& a);   // attn_vit.hip: block-diagonal, hd 72, pre-scaled Q
 int cogs_k_attention_decode(hipStream_t st, const struct CogsAttn& a, float* part_o, float* part_ml);   // attn_decode.hip: one query row, hd 128, key-split partials

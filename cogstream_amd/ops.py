@@ -38,21 +38,26 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          rope_cos: Optional[torch.Tensor] = None, rope_sin: Optional[torch.Tensor] = None, rope_cols: int = 0,
          head_dim: int = 0, rope_lut: Optional[torch.Tensor] = None, rope_rowpos: Optional[torch.Tensor] = None,
          row_stats: Optional[torch.Tensor] = None, ln_ab: Optional[torch.Tensor] = None,
-         col_c: Optional[torch.Tensor] = None, lib=None) -> torch.Tensor:
-    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)  (see cogs_gemm in include/cogs.h). lib: another build of the library
-    (A/B tests only)"""
+         col_c: Optional[torch.Tensor] = None, hm_cols: int = 0, lib=None) -> torch.Tensor:
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)  (see cogs_gemm in include/cogs.h). hm_cols > 0: head-major output -- the
+    result tensor is [N / hm_cols, hm_cols / head_dim, M, head_dim] (cogs_gemm_desc.hm_rows = M). lib: another build of
+    the library (A/B tests only)"""
     _need_cuda(a, w, bias, residual, out)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
     ncols = N // 2 if act == L.ACT_SWIGLU else N
     if out is None:
-        out = torch.empty(M, ncols, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+        if hm_cols > 0:
+            out = torch.empty(N // hm_cols, hm_cols // head_dim, M, head_dim, device=a.device, dtype=a.dtype)
+        else:
+            out = torch.empty(M, ncols, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
     d = L.GemmDesc()
     d.dtype = dtype_code(a.dtype)
     d.A, d.lda = ptr(a), a.stride(0)
     d.W, d.ldw = ptr(w), w.stride(0)
-    d.C, d.ldc = ptr(out), out.stride(0)
+    d.C, d.ldc = ptr(out), (N if hm_cols > 0 else out.stride(0))
+    d.hm_rows, d.hm_cols = (M if hm_cols > 0 else 0), hm_cols
     d.bias = ptr(bias)
     d.residual, d.ldr = ptr(residual), (residual.stride(0) if residual is not None else 0)
     d.M, d.N, d.K = M, N, K
@@ -74,17 +79,25 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hq: int, hkv
               scale: Optional[float] = None, cu_seqlens: Optional[torch.Tensor] = None, max_seqlen: int = 0,
               row_lo: Optional[torch.Tensor] = None, row_hi: Optional[torch.Tensor] = None, bias: float = 0.0,
               causal: bool = False, q_pos0: int = 0, force_rowwise: bool = False, nsplit: int = 1,
-              out: Optional[torch.Tensor] = None, q_prescaled: bool = False, lib=None) -> torch.Tensor:
-    """token-major attention: q [Lq, hq*hd] (may be a column view of a fused buffer), k/v [Lk, hkv*hd]. lib: another build of
-    the library (tests: A/B identity)"""
+              out: Optional[torch.Tensor] = None, q_prescaled: bool = False, head_major: bool = False, lib=None) -> torch.Tensor:
+    """token-major attention: q [Lq, hq*hd] (may be a column view of a fused buffer), k/v [Lk, hkv*hd]. head_major: q, k, v
+    are [heads, L, hd] instead (cogs_attn_desc.head_stride; the output stays token-major). lib: another build of the
+    library (tests: A/B identity)"""
     _need_cuda(q, k, v)
-    Lq, Lk = q.shape[0], k.shape[0]
+    if head_major:
+        assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and q.dim() == 3
+        Lq, Lk = q.shape[1], k.shape[1]
+    else:
+        Lq, Lk = q.shape[0], k.shape[0]
     if out is None:
         out = torch.empty(Lq, hq * head_dim, device=q.device, dtype=q.dtype)
     d = L.AttnDesc()
     d.dtype = dtype_code(q.dtype)
     d.Q, d.K, d.V, d.O = ptr(q), ptr(k), ptr(v), ptr(out)
-    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(-2), k.stride(-2), v.stride(-2), out.stride(0)
+    d.head_stride = q.stride(0) if head_major else 0
+    if head_major:
+        assert k.stride(0) == q.stride(0) == v.stride(0), "one head stride for q, k, v"
     d.cu_seqlens = ptr(cu_seqlens)
     d.nseg = (cu_seqlens.numel() - 1) if cu_seqlens is not None else 1
     d.max_seqlen = max_seqlen

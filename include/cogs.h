@@ -135,6 +135,14 @@ typedef struct {
     float* row_stats;
     const float* ln_ab;
     const float* col_c;
+    /* Head-major output (bf16, M >= 2, no activation / residual / row_stats / fp32 output; what the encoder's QKV GEMM uses):
+     * hm_rows > 0 -> the N columns are N / hm_cols blocks (q | k | v) of hm_cols / head_dim heads each, and element (row m,
+     * column n) is stored at  C[((n / hm_cols) * (hm_cols / head_dim) + (n % hm_cols) / head_dim) * hm_rows * head_dim
+     * + m * head_dim + n % head_dim]  -- [block][head][row][head_dim], every head's rows contiguous (ldc is ignored; M <=
+     * hm_rows; head_dim % 8 == 0; hm_cols % head_dim == 0; N % hm_cols == 0; hm_rows * hm_cols * 2 < 2^32).
+     * cogs_attn_desc.head_stride reads that layout. 0 = row-major C[m][n]. */
+    int64_t hm_rows;
+    int hm_cols;
 } cogs_gemm_desc;
 cogs_status cogs_gemm(cogs_stream stream, const cogs_gemm_desc* d);
 /* (rstd, -rstd * mean) per row from the row_stats partials of a GEMM whose N is the LayerNorm width H */
@@ -161,6 +169,11 @@ typedef struct {
     int nsplit; void* ws; size_t ws_bytes;
     int q_prescaled;        /* Q already carries scale*log2(e) (`scale` is then ignored): lets the bf16 kernels run the
                              * softmax without a per-score multiply; not with row_lo/row_hi */
+    int64_t head_stride;    /* 0: token-major Q / K / V as described above (head h at column h*head_dim of a row). > 0: HEAD-major
+                             * Q, K and V -- head h starts head_stride elements after head h-1 and holds its rows back to back
+                             * (ldq = ldk = ldv = head_dim): the layout cogs_gemm_desc.hm_rows writes (head_stride = hm_rows *
+                             * head_dim). Only the encoder's production shape takes it (bf16, head_dim 72, cu_seqlens, pre-scaled
+                             * Q, hq == hkv, no mask modes); anything else returns COGS_E_UNSUPPORTED. O stays token-major. */
 } cogs_attn_desc;
 cogs_status cogs_attention(cogs_stream stream, const cogs_attn_desc* d);
 

@@ -786,3 +786,71 @@ def L_ACT_NONE():
 def L_ACT_GELU():
     from cogstream_amd import _lib as L
     return L.ACT_GELU_TANH
+
+
+@pytest.mark.parametrize("M,heads,fold", [(96, 2, False), (1300, 2, True), (1300, 7, True), (2048 + 40, 16, True), (6400, 16, False),
+                                          (14824, 16, True)])
+def test_gemm_head_major_output_equals_row_major_bit_for_bit(dev, M, heads, fold):
+    """cogs_gemm_desc.hm_rows (round 5: the encoder's QKV GEMM stores q | k | v as [block][head][row][hd] so that the
+    attention kernel streams whole 128-byte lines): the same epilogue arithmetic, only the store address changes -- the
+    head-major result must be the row-major result re-arranged, bit for bit. heads = 2 / 7: hm_cols is not a multiple of
+    64, so a wave tile straddles q / k / v and every tile takes the general epilogue; heads = 16 (the production width):
+    interior tiles take the lean paired epilogue; M covers the 128x128, 256x128 ring and ping-pong kernels, a ragged last
+    row block, and the round-aligned split (14 824 rows)."""
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(M + heads)
+    hd, K = 72, 1152 if heads == 16 else 128
+    Hc = heads * hd
+    N = 3 * Hc
+    rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).bfloat16()
+    x = rnd(M, K) + 0.25
+    ang = torch.rand(M, hd // 2, generator=g, device=dev) * 6.0
+    table = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+    kw = dict(rope_cos=table, rope_sin=None, rope_cols=2 * Hc, head_dim=hd)
+    if fold:
+        from cogstream_amd.weights import fold_layernorm
+        wf, _, col_c = fold_layernorm(rnd(N, K).cpu(), rnd(N).cpu(), (1 + 0.3 * torch.randn(K)).bfloat16(), (0.2 * torch.randn(K)).bfloat16())
+        xs = x.float()
+        rstd = (xs.var(1, unbiased=False) + 1e-6).rsqrt()
+        ab = torch.stack([rstd, -rstd * xs.mean(1)], 1).contiguous()
+        args = dict(a=x, w=wf.to(dev), bias=None, ln_ab=ab, col_c=col_c.to(dev), **kw)
+    else:
+        args = dict(a=x, w=rnd(N, K), bias=rnd(N), **kw)
+    row = ops.gemm(**args)
+    hm = ops.gemm(**args, hm_cols=Hc)
+    torch.cuda.synchronize()
+    assert hm.shape == (3, heads, M, hd)
+    want = row.view(M, 3, heads, hd).permute(1, 2, 0, 3)
+    assert torch.equal(hm, want), float((hm.float() - want.float()).abs().max())
+
+
+@pytest.mark.parametrize("heads,lens", [(1, [1]), (2, [32, 33]), (1, [63, 64, 65]), (8, [200] * 5), (2, [255, 256, 257]),
+                                        (16, [924, 924]), (3, [1024, 70, 1000]), (16, [130] * 4)])
+@pytest.mark.parametrize("variant", [2, 1])
+def test_attention_head_major_inputs_equal_token_major_bit_for_bit(dev, heads, lens, variant):
+    """cogs_attn_desc.head_stride: the encoder's attention kernels (pipelined LDS-DMA kernel = debug switch attn_vit 2,
+    unpipelined = 1) reading q, k, v as [head][row][72] -- contiguous key tiles, whole-line LDS-DMA pieces -- must give the
+    bits they give on the token-major fused buffer: only the source addresses differ. Ragged last tiles (rows past a
+    segment's end are re-read from its last row, never from the next frame or head), one-row segments, both grid orders."""
+    from cogstream_amd import _lib as L
+    ops = _ops()
+    hd, H = 72, heads * 72
+    n = sum(lens)
+    g = torch.Generator(device=dev).manual_seed(n + heads)
+    qkv = torch.randn(n, 3 * H, generator=g, device=dev)
+    qkv[:, :H] *= LOG2E / math.sqrt(hd)
+    qkv = qkv.bfloat16()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+    with L.debug_switch("attn_vit", variant):
+        tok = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], hq=heads, hkv=heads, head_dim=hd, cu_seqlens=cu,
+                            max_seqlen=max(lens), q_prescaled=True)
+        assert L.debug_get("attn_last_kernel") == (3 if variant == 2 else 2)
+        hm3 = qkv.view(n, 3, heads, hd).permute(1, 2, 0, 3).contiguous()           # [3][heads][n][hd], one buffer
+        # poison everything around the buffer's rows the kernel may not read: a NaN pulled in from a neighbouring head or
+        # frame would survive the masked softmax as 0 * NaN
+        out = ops.attention(hm3[0], hm3[1], hm3[2], hq=heads, hkv=heads, head_dim=hd, cu_seqlens=cu, max_seqlen=max(lens),
+                            q_prescaled=True, head_major=True)
+        assert L.debug_get("attn_last_kernel") == (8 if variant == 2 else 2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(out, tok), float((out.float() - tok.float()).abs().max())
