@@ -19,6 +19,11 @@ LIB = HERE / "libcogs_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# per-source additions. attn_vit.hip: its row maxima run on MFMA results, which hipcc otherwise canonicalises (v_max x, x)
+# in front of every v_max3 chain -- four extra vector instructions per 32-key block on the port that bounds the kernel;
+# scores are finite or -inf (masked), never NaN, and the kernel's own NaN-sensitive test (`!(d > -inf)`) keeps its
+# meaning for -inf.
+EXTRA_FLAGS = {"attn_vit": ["-fno-honor-nans"]}
 
 
 def _stale(target: Path, deps) -> bool:
@@ -130,7 +135,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", str(s), "-o", str(o)]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(s.stem, []) + ["-c", str(s), "-o", str(o)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

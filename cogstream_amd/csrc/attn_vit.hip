@@ -480,12 +480,18 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                      :: "s"(lds), "v"(off_bytes), "s"(base) : "memory");
     };
-    auto issue_tile = [&](int t) {
-        const int kbase = qs + t * 64;
-        const int valid = qe - kbase;                            // >= 1
-        const bf16_t* kb = uniform_ptr(p.K + (long)kbase * p.ldk + head * p.head_stride);
-        const bf16_t* vb = uniform_ptr(p.V + (long)kbase * p.ldv + head * p.head_stride);
-        const unsigned st = __builtin_amdgcn_readfirstlane(smem_lds + (t & (NS - 1)) * STAGE);
+    // tiles are issued strictly in order 0, 1, 2, ...: the source of the next tile is a running pointer (one 64-bit scalar
+    // add per matrix and tile; the round-4 form rebuilt base + row * ld from scratch: six s_mul and four v_readfirstlane
+    // per tile head in every wave)
+    const bf16_t* k_next = p.K + (long)qs * p.ldk + head * p.head_stride;
+    const bf16_t* v_next = p.V + (long)qs * p.ldv + head * p.head_stride;
+    const long tile_step = 64 * p.ldk;                           // elements; ldk == ldv
+    auto issue_tile = [&](int t, int slot) {                     // slot = t & (NS - 1), a constant in the unrolled loop
+        const int valid = qe - (qs + t * 64);                    // >= 1
+        const bf16_t* kb = uniform_ptr(k_next);
+        const bf16_t* vb = uniform_ptr(v_next);
+        k_next += tile_step; v_next += tile_step;
+        const unsigned st = __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE);
         int off[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) off[i] = pc_off[i];
@@ -561,14 +567,19 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             if (key >= valid) sx[r] = -INFINITY;
         }
     };
-    auto blk_max = [&](const f32x16& sx) -> float {
+    // largest score of this lane's 16 keys of a block, and the same over the lane pair (l, l + 32) that shares a query row
+    auto own_max = [&](const f32x16& sx) -> float {
         float d = sx[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) d = fmaxf(d, sx[r]);
+        return d;
+    };
+    auto pair_max = [&](float d) -> float {
         const unsigned db = __builtin_bit_cast(unsigned, d);
         const auto sw = __builtin_amdgcn_permlane32_swap(db, db, false, false);
         return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
     };
+    auto blk_max = [&](const f32x16& sx) -> float { return pair_max(own_max(sx)); };
     auto set_shift = [&](float m_new) {
         sh = m_new;
         const unsigned bits = __float_as_uint(-sh) >> 16;          // exact: sh is a bf16 value
@@ -596,15 +607,15 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #ifdef COGS_PIPE_STAMPS2
     PSTAMP();      // Q loads issued
 #endif
-    issue_tile(0);
+    issue_tile(0, 0);
     // round 4: only Q and tile 0 go out before the first wait (10 vector-memory instructions per wave instead of 18: the
     // CU's vector-memory path takes one 1 KiB piece per ~60-115 cycles, so the 8 pieces of tiles 1 and 2 used to stand
     // between every wave and its first MFMA); tiles 1 and 2 follow behind the barrier, in order, so the counted waits of
     // the tile loop see the same queue as before. (p.early_prefetch: the old order, for A/B runs)
     const bool EARLY = p.early_prefetch != 0;
     if (EARLY) {
-        if (nt > 1) issue_tile(1);
-        if (nt > 2) issue_tile(2);
+        if (nt > 1) issue_tile(1, 1);
+        if (nt > 2) issue_tile(2, 2);
     }
 #ifdef COGS_PIPE_STAMPS2
     PSTAMP();      // tiles issued
@@ -616,8 +627,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     PSTAMP();      // 1: Q and tile 0 landed
     __builtin_amdgcn_s_barrier();
     if (!EARLY) {
-        if (nt > 1) issue_tile(1);
-        if (nt > 2) issue_tile(2);
+        if (nt > 1) issue_tile(1, 1);
+        if (nt > 2) issue_tile(2, 2);
     }
     f32x16 sa, sb;
     u32x4 kf[KS];                                                     // K fragments of the NEXT block to be multiplied
@@ -672,10 +683,16 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         if constexpr (KIND != 0) {
             const int valid_next = len - 32 * (j + 1);
             if constexpr (KIND == 3) mask_blk(sn, valid_next);
-            const float d = blk_max(sn);
-            if (__any(d > RESCALE_THR)) {
+            // the test is wave-uniform (ANY lane above the threshold), so the common path does not combine the two lanes of a
+            // row: 7 v_max3 + 1 v_max on the lane's own 16 scores; the exchange with the partner lane (v_mov, wait states,
+            // v_permlane32_swap, two more v_max) only runs on the rare path. Round 5, with -fno-honor-nans for this file (no
+            // canonicalising v_max in front of every chain): 17 -> 8 vector instructions per 32-key block on the port this
+            // kernel is bound by (per tile and wave: 22 MFMA x 8 issue cycles + 32 v_exp x 8 + 16 v_cvt_pk + the maxima)
+            const float d_own = own_max(sn);
+            if (__any(d_own > RESCALE_THR)) {
                 // rare (wave-uniform): move the reference of the rows that need it; O, now complete up to block j, is
                 // multiplied by 2^-(m_new - sh) and S(j+1) is simply computed again with the new shift
+                const float d = pair_max(d_own);
                 const float m_new = d > RESCALE_THR ? bf16_round(sh + d) : sh;
                 const float al = __builtin_amdgcn_exp2f(sh - m_new);
 #pragma unroll
@@ -690,12 +707,13 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             }
         }
     };
-    auto tile_head = [&](const int t) {
+    auto tile_head = [&](const int t, auto slot_tag) {       // slot_tag: ring slot of tile t when known at compile time, else -1
+        constexpr int SLOT = decltype(slot_tag)::value;
         // outstanding, oldest first: tile t+1 (if any), tile t+2 (if any); tile t+1 must have landed
         wait_tiles(t + 2 < nt ? 1 : 0);
         __builtin_amdgcn_s_barrier();     // K(t+1), V(t) visible to all; slot of tile t-1 no longer read by anyone
 #ifndef ABL_NOLOAD
-        if (t + 3 < nt) issue_tile(t + 3);
+        if (t + 3 < nt) issue_tile(t + 3, SLOT >= 0 ? (SLOT + 3) & (NS - 1) : (t + 3) & (NS - 1));
 #endif
     };
 
@@ -706,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     // four tiles per trip: t is a multiple of 4 here, so tile t + i sits in ring slot i (compile-time LDS addresses)
     for (; 2 * (t + 3) + 2 < nfull; t += 4) {
 #define COGS_AV_TILE(I)                                                                                      \
-        tile_head(t + I);                                                                                    \
+        tile_head(t + I, std::integral_constant<int, I>{});                                                  \
         if (wave_active) {                                                                                   \
             substep(sa, sb, 2 * (t + I), Full{}, std::integral_constant<int, I>{});                          \
             substep(sb, sa, 2 * (t + I) + 1, Full{}, std::integral_constant<int, I>{});                      \
@@ -716,7 +734,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     }
 #endif
     for (; 2 * t + 2 < nfull; ++t) {              // blocks 2t+1 and 2t+2 are full
-        tile_head(t);
+        tile_head(t, std::integral_constant<int, -1>{});
 #ifndef ABL_NOCOMPUTE
         if (wave_active) {
             substep(sa, sb, 2 * t, Full{}, std::integral_constant<int, -1>{});
@@ -726,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     }
     PSTAMP();      // 3: main loop done
     for (; t < nt; ++t) {                         // the ragged end: block kinds decided at run time (wave-uniform)
-        tile_head(t);
+        tile_head(t, std::integral_constant<int, -1>{});
         if (!wave_active) continue;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {

@@ -94,10 +94,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hq: int, hkv
     d = L.AttnDesc()
     d.dtype = dtype_code(q.dtype)
     d.Q, d.K, d.V, d.O = ptr(q), ptr(k), ptr(v), ptr(out)
-    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(-2), k.stride(-2), v.stride(-2), out.stride(0)
-    d.head_stride = q.stride(0) if head_major else 0
-    if head_major:
-        assert k.stride(0) == q.stride(0) == v.stride(0), "one head stride for q, k, v"
+    if head_major:      # contiguous [heads, L, hd] tensors (strides of size-1 dimensions are not trusted)
+        assert Lq == Lk and q.shape == k.shape == v.shape, "one head stride for q, k, v"
+        d.ldq = d.ldk = d.ldv = head_dim
+        d.ldo = out.stride(0)
+        d.head_stride = Lq * head_dim
+    else:
+        d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+        d.head_stride = 0
     d.cu_seqlens = ptr(cu_seqlens)
     d.nseg = (cu_seqlens.numel() - 1) if cu_seqlens is not None else 1
     d.max_seqlen = max_seqlen
