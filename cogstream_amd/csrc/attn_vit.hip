@@ -388,9 +388,15 @@ __global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
 // each time the tile loop lost more (hoisted per-item scalars: 60-80 spilled SGPRs, spilled VGPRs whose reloads count
 // on vmcnt; a static item order instead of the dispatcher's dynamic one) than the seam gave back: 0.42-0.44 ms against
 // 0.40 ms per layer in the same run. Removed.
+// Round 5, measured and removed: the same kernel with EIGHT waves per workgroup (256 query rows, one workgroup per CU: every
+// K/V tile staged once for twice the rows, 2.25 instead of 4.5 LDS-DMA pieces per wave and tile, half as many workgroup
+// entries per (frame, head)). Bit-identical outputs; attention of a cfg2 step 9.84 -> 11.03 ms, cfg3 4.26 -> 4.78 ms
+// (in-process A/B, tools/encoder_ab.py): with one workgroup per CU nothing computes during a workgroup's entry and exit
+// (13-15 % of its life, stamps below), and the two waves of a SIMD, now in one workgroup, are put back in step by every
+// tile barrier. Two 4-wave workgroups per CU it stays.
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
-    constexpr int NT = 256, QB = 128, NS = 4;
+    constexpr int NT = 256, QB = 128, NS = 4, NW = 4;
     static_assert(HD % 8 == 0 && HD % 16 == 8 && HD < 96, "pad column HD must open a fresh 16-byte chunk inside the last k-step");
     constexpr int KS = (HD + 8) / 16, DB = (HD + 8 + 31) / 32, CH = HD / 8;
     constexpr int RS = HD * 2;                        // LDS row stride = the row itself (144 B)
@@ -455,12 +461,14 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     }
 
     // DMA pieces: piece j (0..8) of a matrix covers chunks 64j..64j+63 of the tile image (chunk c = row c / 9, 16-byte
-    // column c % 9). Wave w issues pieces w and w + 4 of K and of V; piece 8 of K goes to wave 0, of V to wave 1.
-    const int n_own = wid < 2 ? 5 : 4;                           // this wave's DMA instructions per tile
-    int pc_row[3], pc_off[3];                                    // per-lane row and byte offset of the wave's pieces
+    // column c % 9). Wave w issues pieces w, w + NW, ... < 8 of K and of V (two each with 4 waves, one with 8); piece 8 of
+    // K goes to wave 0, of V to wave 1.
+    constexpr int NPI = 8 / NW;                                  // regular pieces per matrix and wave
+    const int n_own = 2 * NPI + (wid < 2 ? 1 : 0);               // this wave's DMA instructions per tile
+    int pc_row[NPI + 1], pc_off[NPI + 1];                        // per-lane row and byte offset of the wave's pieces
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int c = (i < 2 ? wid + 4 * i : 8) * 64 + lane;
+    for (int i = 0; i < NPI + 1; ++i) {
+        const int c = (i < NPI ? wid + NW * i : 8) * 64 + lane;
         pc_row[i] = c / CH;
         pc_off[i] = (pc_row[i] * (int)p.ldk + (c % CH) * 8) * 2;   // bytes; ldk == ldv (checked by the launcher). Head-major
     }                                                              // (ldk = HD): = 16 c, the piece is one contiguous KiB
@@ -492,26 +500,26 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         const bf16_t* vb = uniform_ptr(v_next);
         k_next += tile_step; v_next += tile_step;
         const unsigned st = __builtin_amdgcn_readfirstlane(smem_lds + slot * STAGE);
-        int off[3];
+        int off[NPI + 1];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) off[i] = pc_off[i];
+        for (int i = 0; i < NPI + 1; ++i) off[i] = pc_off[i];
         if (valid < 64) {                                        // ragged last tile: rows past the end repeat the last row
 #pragma unroll
-            for (int i = 0; i < 3; ++i) off[i] = pc_off[i] - (pc_row[i] - min(pc_row[i], valid - 1)) * (int)p.ldk * 2;
+            for (int i = 0; i < NPI + 1; ++i) off[i] = pc_off[i] - (pc_row[i] - min(pc_row[i], valid - 1)) * (int)p.ldk * 2;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            dma16(kb, off[i], st + (wid + 4 * i) * 1024);
-            dma16(vb, off[i], st + TILE + (wid + 4 * i) * 1024);
+        for (int i = 0; i < NPI; ++i) {
+            dma16(kb, off[i], st + (wid + NW * i) * 1024);
+            dma16(vb, off[i], st + TILE + (wid + NW * i) * 1024);
         }
-        if (wid == 0) dma16(kb, off[2], st + 8 * 1024);
-        if (wid == 1) dma16(vb, off[2], st + TILE + 8 * 1024);
+        if (wid == 0) dma16(kb, off[NPI], st + 8 * 1024);
+        if (wid == 1) dma16(vb, off[NPI], st + TILE + 8 * 1024);
     };
-    // this wave's pieces of every tile but the `newer` most recently issued ones have landed
+    // this wave's pieces of every tile but the `newer` most recently issued ones have landed (n_own = 2 NPI or 2 NPI + 1)
     auto wait_tiles = [&](int newer) {
         if (newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (newer == 1) { if (n_own == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else { if (n_own == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else if (newer == 1) { if (n_own == 2 * NPI + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPI + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPI) : "memory"); }
+        else { if (n_own == 2 * NPI + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NPI + 2) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NPI) : "memory"); }
     };
 
     // per-lane LDS read offsets inside a stage. K: lane (key r32, k-half h) reads 16 bytes at column 32 ks + 16 h; in
@@ -723,9 +731,14 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #ifndef AV_NO_UNROLL4
     // four tiles per trip: t is a multiple of 4 here, so tile t + i sits in ring slot i (compile-time LDS addresses)
     for (; 2 * (t + 3) + 2 < nfull; t += 4) {
+#ifdef ABL_NOCOMPUTE
+#define COGS_AV_ACTIVE false
+#else
+#define COGS_AV_ACTIVE wave_active
+#endif
 #define COGS_AV_TILE(I)                                                                                      \
         tile_head(t + I, std::integral_constant<int, I>{});                                                  \
-        if (wave_active) {                                                                                   \
+        if (COGS_AV_ACTIVE) {                                                                                \
             substep(sa, sb, 2 * (t + I), Full{}, std::integral_constant<int, I>{});                          \
             substep(sb, sa, 2 * (t + I) + 1, Full{}, std::integral_constant<int, I>{});                      \
         }
@@ -808,6 +821,9 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     const int env_early = (int)g_cogs_debug.attn_vit_early;
     p.early_prefetch = env_early;
     if (variant == 1 || a.ldk != a.ldv) { g_cogs_debug.attn_last_kernel = 2; hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p); }
-    else { g_cogs_debug.attn_last_kernel = a.head_stride > 0 ? 8 : 3; hipLaunchKernelGGL(attn_vit_pipe_kernel<72>, grid, dim3(256), 0, st, p); }
+    else {
+        g_cogs_debug.attn_last_kernel = a.head_stride > 0 ? 8 : 3;
+        hipLaunchKernelGGL(attn_vit_pipe_kernel<72>, grid, dim3(256), 0, st, p);
+    }
     return COGS_LAUNCH_CHECK();
 }

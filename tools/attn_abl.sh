@@ -7,7 +7,7 @@ O=$R/gpurun_out/attn_abl; mkdir -p $O
 cd $R
 i=0
 for v in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 $v -I cogstream_amd/csrc tools/micro/attn_vit_micro.cpp -o $O/m_$i 2> $O/build_$i.log || { echo "build failed $v"; tail -5 $O/build_$i.log; }
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fno-honor-nans --offload-arch=gfx950 $v -I cogstream_amd/csrc tools/micro/attn_vit_micro.cpp -o $O/m_$i 2> $O/build_$i.log || { echo "build failed $v"; tail -5 $O/build_$i.log; }
   i=$((i+1))
 done
 for rep in 1 2; do

@@ -1,6 +1,8 @@
 // Stand-alone timing / stamp harness for csrc/attn_vit.hip (ViT block-diagonal attention, hd 72):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DCOGS_ATTN_STAMPS] -I cogstream_amd/csrc tools/micro/attn_vit_micro.cpp -o tools/micro/attn_vit_micro
+//   attn_vit_micro [frames] [rows per frame] [layout: 0 token-major fused qkv, 1 head-major q | k | v]
 #include "../../cogstream_amd/csrc/attn_vit.hip"
+CogsDebug g_cogs_debug;
 #include <cstdio>
 #include <cstring>
 #include <cmath>
@@ -8,6 +10,7 @@
 #include <random>
 int main(int argc, char** argv) {
     const int nseg = argc > 1 ? atoi(argv[1]) : 64, seg = argc > 2 ? atoi(argv[2]) : 924, heads = 16, hd = 72;
+    const int hm = argc > 3 ? atoi(argv[3]) : 1;
     const long L = (long)nseg * seg, H = heads * hd;
     std::vector<uint16_t> h(L * 3 * H);
     std::mt19937 rng(1);
@@ -19,11 +22,23 @@ int main(int argc, char** argv) {
         }
     uint16_t *qkv, *out; int* cu;
     hipMalloc(&qkv, h.size() * 2); hipMalloc(&out, L * H * 2); hipMalloc(&cu, (nseg + 1) * 4);
+    if (hm) {      // [row][q | k | v][head][hd] -> [q | k | v][head][row][hd]
+        std::vector<uint16_t> t(h.size());
+        for (long i = 0; i < L; ++i)
+            for (int w = 0; w < 3; ++w)
+                for (int hh = 0; hh < heads; ++hh)
+                    std::memcpy(&t[((long)(w * heads + hh) * L + i) * hd], &h[i * 3 * H + w * H + hh * hd], hd * 2);
+        h.swap(t);
+    }
     hipMemcpy(qkv, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     std::vector<int> hc(nseg + 1); for (int i = 0; i <= nseg; ++i) hc[i] = i * seg;
     hipMemcpy(cu, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
     CogsAttn a; a.dtype = COGS_DT_BF16; a.Q = qkv; a.K = qkv + H; a.V = qkv + 2 * H; a.O = out;
     a.ldq = a.ldk = a.ldv = 3 * H; a.ldo = H; a.cu_seqlens = cu; a.nseg = nseg; a.max_seqlen = seg;
+    a.uniform_seqlen = seg;
+    if (hm) {
+        a.K = qkv + L * H; a.V = qkv + 2 * L * H; a.ldq = a.ldk = a.ldv = hd; a.head_stride = L * hd;
+    }
     a.q_len = a.kv_len = (int)L; a.hq = a.hkv = heads; a.head_dim = hd; a.q_prescaled = 1;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) cogs_k_attention_vit(0, a);
