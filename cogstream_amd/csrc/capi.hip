@@ -43,8 +43,9 @@ struct cogs_ctx {
     bool stage_busy[STAGE_SLOTS] = {false, false, false, false};
     int stage_next = 0;
     // second stream of the frame-split encode (cogs_vit_encode): two halves of a small clip run side by side
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipStream_t> aux_streams;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_joins;
     int vit_streams = 2;                  // cogs_vit_set_streams: 1 = never split
     // optional per-kernel-class event profiling (bench/roofline only)
     bool prof_on = false;
@@ -225,9 +226,9 @@ cogs_status cogs_destroy(cogs_handle h) {
     }
     if (h->vit_inv_freq) (void)hipFree(h->vit_inv_freq);
     if (h->llm_inv_freq) (void)hipFree(h->llm_inv_freq);
-    if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+    for (hipStream_t s2 : h->aux_streams) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (hipEvent_t e : h->ev_joins) (void)hipEventDestroy(e);
     delete h;
     return COGS_OK;
 }
@@ -446,7 +447,7 @@ static size_t vit_carve(const cogs_vit_weights& w, int64_t N, int nframes, Carve
 }
 
 cogs_status cogs_vit_set_streams(cogs_handle h, int streams) {
-    if (!h || streams < 1 || streams > 2) return COGS_E_INVALID;
+    if (!h || streams < 1 || streams > 4) return COGS_E_INVALID;
     h->vit_streams = streams;
     return COGS_OK;
 }
@@ -456,14 +457,34 @@ cogs_status cogs_vit_workspace_bytes(cogs_handle h, int64_t n_patches, size_t* b
     Carver c(nullptr, 0);
     void *a, *b, *d, *e; float *rc, *rs; int32_t *cu, *lo, *hi;
     // frames <= patches; size the cu_seqlens array for the worst case
-    // + room for the second set of fixed-size tables when a small clip is encoded as two halves (cogs_vit_encode)
-    *bytes = vit_carve(h->vit, n_patches, (int)n_patches, c, &a, &b, &d, &e, &rc, &rs, &cu, &lo, &hi) + 64 * 1024;
+    // + room for the further sets of fixed-size tables when a clip is encoded as up to four frame ranges (cogs_vit_encode)
+    *bytes = vit_carve(h->vit, n_patches, (int)n_patches, c, &a, &b, &d, &e, &rc, &rs, &cu, &lo, &hi) + 256 * 1024;
     return COGS_OK;
 }
 
-static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* pixel_values, int pix_dtype,
-                                    const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
-                                    void* out_tokens, void* ws, size_t ws_bytes);
+// One contiguous run of frames of a clip on one stream. The encoder is queued in three kinds of step -- begin (tables,
+// patch embedding), layer(l), finish (post-LayerNorm + merge) -- so that cogs_vit_encode can ALTERNATE the steps of several
+// ranges between their streams: queued one whole range after the other (rounds 3-4), the second stream's first kernel
+// reached the GPU ~250 launches = 0.9 ms after the first stream's, and ran that much alone at the end -- a tenth of a
+// frame-sharded rank's 8.5 ms step.
+struct VitRange {
+    cogs_handle h; hipStream_t st;
+    const void* pixel_values; int pix_dtype;
+    std::vector<int64_t> grid, merge;     // [V][3], [V]
+    int attn_mode; void* out_tokens; void* ws; size_t ws_bytes;
+    // derived by begin()
+    int64_t N = 0; int nframes = 0, V = 0;
+    void *xpad = nullptr, *x = nullptr, *ln = nullptr, *big = nullptr;
+    float *rc = nullptr, *rs = nullptr, *lut = nullptr, *stat_part = nullptr, *ln_ab = nullptr;
+    int32_t *cu = nullptr, *lo = nullptr, *hi = nullptr;
+    bool fold = false, use_lut = false, prescale_q = false, head_major = false;
+    int maxpos = 0, max_seq = 0, uniform_seq = 0;
+    float scale = 1.f;
+
+    cogs_status begin();
+    cogs_status layer(int l);
+    cogs_status finish();
+};
 
 // Frames are independent under block-diagonal attention (per-frame attention, RoPE and 2x2 merge:
 // modeling_videollama3_encoder.py:309-312,427,487-501), so a clip is encoded as two halves on two streams: the second
@@ -486,73 +507,100 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
         N += t * gh * gw;
         nframes += t;
     }
+    const cogs_vit_weights& w = h->vit;
+    auto whole = [&]() {
+        VitRange r{h, st, pixel_values, pix_dtype, std::vector<int64_t>(grid_sizes, grid_sizes + 3 * V),
+                   std::vector<int64_t>(merge_sizes, merge_sizes + V), attn_mode, out_tokens, ws, ws_bytes};
+        COGS_TRY(r.begin());
+        for (int l = 0; l < w.layers; ++l) COGS_TRY(r.layer(l));
+        return r.finish();
+    };
     const int64_t split_max = g_cogs_debug.vit_split_max;
-    if (h->vit_streams > 1 && !h->prof_on && attn_mode == COGS_ATTN_BLOCK_DIAG && nframes >= 2 && N <= split_max) {
-        // cut at the frame boundary nearest to half the patches
-        std::vector<int64_t> ga, gb, ma, mb;
-        int64_t rows_a = 0, toks_a = 0, fa = 0, best_gap = N + 1, acc = 0;
-        int cut_v = 0; int64_t cut_t = 0;
-        for (int v = 0; v < V; ++v) {
-            const int64_t per = grid_sizes[3 * v + 1] * grid_sizes[3 * v + 2];
-            for (int64_t f = 0; f <= grid_sizes[3 * v]; ++f) {
-                const int64_t r = acc + f * per;
-                const int64_t gap = r > N - r ? 2 * r - N : N - 2 * r;
-                if (r > 0 && r < N && gap < best_gap) { best_gap = gap; cut_v = v; cut_t = f; }
+    int S = h->vit_streams;
+    if (S > nframes) S = (int)nframes;
+    if (S < 2 || h->prof_on || attn_mode != COGS_ATTN_BLOCK_DIAG || N > split_max) return whole();
+
+    // cut the frames into S contiguous runs at the frame boundaries nearest to r / S of the patches
+    std::vector<VitRange> R;
+    {
+        std::vector<int64_t> frame_rows, frame_v;       // per frame: patches, video
+        for (int v = 0; v < V; ++v)
+            for (int64_t f = 0; f < grid_sizes[3 * v]; ++f) { frame_rows.push_back(grid_sizes[3 * v + 1] * grid_sizes[3 * v + 2]); frame_v.push_back(v); }
+        std::vector<int64_t> cum(nframes + 1, 0);
+        for (int64_t f = 0; f < nframes; ++f) cum[f + 1] = cum[f] + frame_rows[f];
+        std::vector<int64_t> cuts(1, 0);
+        for (int r = 1; r < S; ++r) {
+            int64_t best = cuts.back() + 1;
+            for (int64_t f = cuts.back() + 1; f <= nframes - (S - r); ++f)
+                if (llabs(cum[f] * S - N * r) < llabs(cum[best] * S - N * r)) best = f;
+            cuts.push_back(best);
+        }
+        cuts.push_back(nframes);
+        size_t ws_off = 0;
+        int64_t tok_off = 0;
+        const size_t pes = pix_dtype == COGS_DT_BF16 ? 2 : 4;
+        bool ok = ws != nullptr;
+        for (int r = 0; r < S && ok; ++r) {
+            VitRange q{h, nullptr, (const char*)pixel_values + (size_t)cum[cuts[r]] * w.patch_dim * pes, pix_dtype, {}, {}, attn_mode,
+                       (char*)out_tokens + (size_t)tok_off * w.hidden * esize(w.dtype), (char*)ws + ws_off, 0};
+            int64_t rows = 0, toks = 0;
+            for (int64_t f = cuts[r]; f < cuts[r + 1]; ++f) {       // frames -> (t, gh, gw) runs per video
+                const int v = (int)frame_v[f];
+                if (!q.merge.empty() && q.grid[q.grid.size() - 2] == grid_sizes[3 * v + 1] && q.grid.back() == grid_sizes[3 * v + 2] &&
+                    f > cuts[r] && frame_v[f - 1] == v) ++q.grid[q.grid.size() - 3];
+                else { q.grid.insert(q.grid.end(), {1, grid_sizes[3 * v + 1], grid_sizes[3 * v + 2]}); q.merge.push_back(merge_sizes[v]); }
+                rows += frame_rows[f];
+                toks += frame_rows[f] / (merge_sizes[v] * merge_sizes[v]);
             }
-            acc += grid_sizes[3 * v] * per;
+            Carver c(nullptr, 0);
+            void *p0, *p1, *p2, *p3; float *q0, *q1; int32_t *i0, *i1, *i2;
+            q.ws_bytes = vit_carve(w, rows, (int)(cuts[r + 1] - cuts[r]), c, &p0, &p1, &p2, &p3, &q0, &q1, &i0, &i1, &i2);
+            ws_off += q.ws_bytes;
+            tok_off += toks;
+            ok = ws_off <= ws_bytes && rows > 0;
+            R.push_back(std::move(q));
         }
-        for (int v = 0; v < V; ++v) {
-            const int64_t t = grid_sizes[3 * v], gh = grid_sizes[3 * v + 1], gw = grid_sizes[3 * v + 2], ms = merge_sizes[v];
-            const int64_t ta = v < cut_v ? t : (v == cut_v ? cut_t : 0), tb = t - ta;
-            if (ta > 0) { ga.insert(ga.end(), {ta, gh, gw}); ma.push_back(ms); rows_a += ta * gh * gw; toks_a += ta * gh * gw / (ms * ms); fa += ta; }
-            if (tb > 0) { gb.insert(gb.end(), {tb, gh, gw}); mb.push_back(ms); }
-        }
-        const cogs_vit_weights& w = h->vit;
-        Carver ca(nullptr, 0), cb(nullptr, 0);
-        void *p0, *p1, *p2, *p3; float *q0, *q1; int32_t *i0, *i1, *i2;
-        const size_t need_a = vit_carve(w, rows_a, (int)fa, ca, &p0, &p1, &p2, &p3, &q0, &q1, &i0, &i1, &i2);
-        const size_t need_b = vit_carve(w, N - rows_a, (int)(nframes - fa), cb, &p0, &p1, &p2, &p3, &q0, &q1, &i0, &i1, &i2);
-        bool ok = ws && need_a + need_b <= ws_bytes && !ma.empty() && !mb.empty();
-        if (ok && !h->aux_stream) {
-            hipStream_t s2 = nullptr;
-            hipEvent_t e1 = nullptr, e2 = nullptr;
-            ok = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
-            if (ok) { h->aux_stream = s2; h->ev_fork = e1; h->ev_join = e2; }
-            else {      // whatever was created goes back; the clip is encoded on the caller's stream alone
-                if (e2) (void)hipEventDestroy(e2);
-                if (e1) (void)hipEventDestroy(e1);
-                if (s2) (void)hipStreamDestroy(s2);
-            }
-        }
-        if (ok) {
-            const size_t pes = pix_dtype == COGS_DT_BF16 ? 2 : 4;
-            if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0) != hipSuccess) return COGS_E_HIP;
-            cogs_k_gemm_co_streams(2);
-            const cogs_status ra = vit_encode_range(h, st, pixel_values, pix_dtype, ga.data(), ma.data(), (int)ma.size(), attn_mode,
-                                                    out_tokens, ws, need_a);
-            const cogs_status rb = vit_encode_range(h, h->aux_stream, (const char*)pixel_values + (size_t)rows_a * w.patch_dim * pes,
-                                                    pix_dtype, gb.data(), mb.data(), (int)mb.size(), attn_mode,
-                                                    (char*)out_tokens + (size_t)toks_a * w.hidden * esize(w.dtype),
-                                                    (char*)ws + need_a, need_b);
-            cogs_k_gemm_co_streams(1);
-            // join unconditionally: the caller's stream must not run ahead of anything queued on the second one
-            if (hipEventRecord(h->ev_join, h->aux_stream) != hipSuccess || hipStreamWaitEvent(st, h->ev_join, 0) != hipSuccess) return COGS_E_HIP;
-            return ra != COGS_OK ? ra : rb;
-        }
+        if (!ok) return whole();
     }
-    return vit_encode_range(h, st, pixel_values, pix_dtype, grid_sizes, merge_sizes, V, attn_mode, out_tokens, ws, ws_bytes);
+    while ((int)h->aux_streams.size() < S - 1) {          // streams and events of the handle, created once
+        hipStream_t s2 = nullptr;
+        hipEvent_t e2 = nullptr;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) {
+            if (s2) (void)hipStreamDestroy(s2);       // whatever was created goes back; the clip is encoded on the caller's stream alone
+            return whole();
+        }
+        h->aux_streams.push_back(s2);
+        h->ev_joins.push_back(e2);
+    }
+    if (!h->ev_fork && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return whole();
+    if (hipEventRecord(h->ev_fork, st) != hipSuccess) return COGS_E_HIP;
+    R[0].st = st;
+    for (int r = 1; r < S; ++r) {
+        R[r].st = h->aux_streams[r - 1];
+        if (hipStreamWaitEvent(R[r].st, h->ev_fork, 0) != hipSuccess) return COGS_E_HIP;
+    }
+    cogs_k_gemm_co_streams(S);
+    cogs_status rc = COGS_OK;
+    for (int r = 0; r < S && rc == COGS_OK; ++r) rc = R[r].begin();
+    for (int l = 0; l < w.layers && rc == COGS_OK; ++l)
+        for (int r = 0; r < S && rc == COGS_OK; ++r) rc = R[r].layer(l);
+    for (int r = 0; r < S && rc == COGS_OK; ++r) rc = R[r].finish();
+    cogs_k_gemm_co_streams(1);
+    // join unconditionally: the caller's stream must not run ahead of anything queued on the other ones
+    for (int r = 1; r < S; ++r)
+        if (hipEventRecord(h->ev_joins[r - 1], R[r].st) != hipSuccess || hipStreamWaitEvent(st, h->ev_joins[r - 1], 0) != hipSuccess) return COGS_E_HIP;
+    return rc;
 }
 
-static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* pixel_values, int pix_dtype,
-                                    const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
-                                    void* out_tokens, void* ws, size_t ws_bytes) {
+cogs_status VitRange::begin() {
     const cogs_vit_weights& w = h->vit;
     const int dt = w.dtype;
-    const size_t es = esize(dt);
     const int H = w.hidden, hd = H / w.heads;
-    int64_t N = 0; int nframes = 0;
+    V = (int)merge.size();
+    const int64_t* grid_sizes = grid.data();
+    const int64_t* merge_sizes = merge.data();
+    N = 0; nframes = 0;
     for (int v = 0; v < V; ++v) {
         const int64_t t = grid_sizes[3 * v], gh = grid_sizes[3 * v + 1], gw = grid_sizes[3 * v + 2], ms = merge_sizes[v];
         if (t <= 0 || gh <= 0 || gw <= 0 || ms <= 0 || gh % ms || gw % ms) return COGS_E_INVALID;
@@ -561,36 +609,32 @@ static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* p
     }
     if (N > 0x7fffffff) return COGS_E_INVALID;
     Carver c(ws, ws_bytes);
-    void *xpad, *x, *ln, *big; float *rc, *rs; int32_t *cu, *lo, *hi;
     const size_t need = vit_carve(w, N, nframes, c, &xpad, &x, &ln, &big, &rc, &rs, &cu, &lo, &hi);
     if (!ws || ws_bytes < need) return COGS_E_WORKSPACE;
-    char* qkv = (char*)big;
-    char* att = qkv + (size_t)N * 3 * H * es;
     // LayerNorm folded into the GEMMs (bf16 production path, cogs_vit_layer.qkv_c ...): the buffer that would hold LN(x)
     // carries the per-row partial statistics [N][H/64][2] and the per-row (rstd, -rstd*mean) [N][2] instead
-    bool fold = dt == COGS_DT_BF16 && H % 64 == 0;
+    fold = dt == COGS_DT_BF16 && H % 64 == 0;
     for (int l = 0; l < w.layers && fold; ++l) {
         const cogs_vit_layer& L = h->vit_layers[l];
         fold = L.qkv_c && L.fc1_c;
     }
-    float* stat_part = (float*)ln;
-    float* ln_ab = stat_part + (size_t)N * (H / 64) * 2;
+    stat_part = (float*)ln;
+    ln_ab = stat_part + (size_t)N * (H / 64) * 2;
 
     // rotary position LUT for the ping-pong QKV GEMM (bf16, block-diagonal): (cos, sin)[pos][freq], kept in LDS there
-    int maxpos = 0;
+    maxpos = 0;
     for (int v = 0; v < V; ++v) {
         const int gh = (int)grid_sizes[3 * v + 1], gw = (int)grid_sizes[3 * v + 2];
         maxpos = gh > maxpos ? gh : maxpos;
         maxpos = gw > maxpos ? gw : maxpos;
     }
-    float* lut = (float*)(hi + N);   // carved right behind `hi` (vit_carve)
+    lut = (float*)(hi + N);   // carved right behind `hi` (vit_carve)
     lut = (float*)(((uintptr_t)lut + 255) & ~(uintptr_t)255);
-    const bool use_lut = dt == COGS_DT_BF16 && attn_mode == COGS_ATTN_BLOCK_DIAG && hd % 4 == 0 &&
-                         maxpos * (hd / 4) * 8 <= 27 * 1024;
+    use_lut = dt == COGS_DT_BF16 && attn_mode == COGS_ATTN_BLOCK_DIAG && hd % 4 == 0 && maxpos * (hd / 4) * 8 <= 27 * 1024;
 
     // cu_seqlens (:439-440), same-frame ranges for the eager-global mode, rotary tables (:405-434): all written by
     // kernels on `st` from the grid -- no host staging, so back-to-back encodes with different grids cannot race
-    int max_seq = 0, uniform_seq = 0;
+    max_seq = 0; uniform_seq = 0;
     {
         bool alike = true;
         for (int v = 1; v < V; ++v)
@@ -626,86 +670,100 @@ static cogs_status vit_encode_range(cogs_handle h, hipStream_t st, const void* p
         if (fold) g.row_stats = stat_part;
         { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
     }
-    const float scale = 1.0f / sqrtf((float)hd);
+    scale = 1.0f / sqrtf((float)hd);
     // bf16 MFMA attention kernels take Q pre-multiplied by scale*log2(e): the QKV GEMM epilogue folds the factor in
     // before its single rounding (same relative rounding error as rounding q itself) and the softmax needs no
     // per-score multiply. Not in the parity modes (fp32, or the eager-global bias mode).
-    const bool prescale_q = dt == COGS_DT_BF16 && attn_mode == COGS_ATTN_BLOCK_DIAG && (hd == 72 || hd == 128);
+    prescale_q = dt == COGS_DT_BF16 && attn_mode == COGS_ATTN_BLOCK_DIAG && (hd == 72 || hd == 128);
     // Round 5: the production path keeps q, k, v HEAD-major between the QKV GEMM and the attention kernel --
     // [q | k | v][head][row][hd] in the same N x 3H elements -- so that a (frame, head) block of K / V is one contiguous
     // run and the attention kernel's LDS-DMA pieces are whole 128-byte lines (csrc/gemm_epilogue.h EPI_HM, csrc/attn_vit.hip).
     // Only that kernel reads the layout; the parity modes (fp32, eager-global) stay token-major.
-    const bool head_major = prescale_q && hd == 72 && g_cogs_debug.gemm_headmajor != 0 && g_cogs_debug.attn_vit != 0 &&
-                            (double)N * H * 2.0 < 4294967296.0;
-    for (int l = 0; l < w.layers; ++l) {
-        const cogs_vit_layer& L = h->vit_layers[l];
-        if (fold) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_ln_finalize(st, stat_part, (int)N, H / 64, H, w.ln_eps, ln_ab)); }
-        else { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln1_g, L.ln1_b, (int)N, H, w.ln_eps)); }
-        {
-            CogsGemm g; g.dtype = dt;
-            g.A = fold ? x : ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = 3 * H;
-            g.M = (int)N; g.N = 3 * H; g.K = H;
-            if (fold) { g.ln_ab = ln_ab; g.col_c = L.qkv_c; }
-            else g.bias = L.qkv_b;
-            g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = 2 * H; g.head_dim = hd;
-            if (prescale_q) { g.q_scale = scale * 1.4426950408889634f; g.q_cols = H; }
-            if (use_lut) { g.rope_lut = lut; g.rope_rowpos = lo; g.rope_maxpos = maxpos; }
-            if (head_major) { g.hm_rows = N; g.hm_cols = H; }
-            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
-        }
-        {
-            CogsAttn a; a.dtype = dt;
-            a.Q = qkv; a.K = qkv + (size_t)H * es; a.V = qkv + (size_t)2 * H * es; a.O = att;
-            a.ldq = a.ldk = a.ldv = 3 * H; a.ldo = H;
-            if (head_major) {
-                a.K = qkv + (size_t)N * H * es; a.V = qkv + (size_t)2 * N * H * es;
-                a.ldq = a.ldk = a.ldv = hd; a.head_stride = (long)N * hd;
-            }
-            a.q_len = (int)N; a.kv_len = (int)N; a.hq = a.hkv = w.heads; a.head_dim = hd; a.scale = scale;
-            a.q_prescaled = prescale_q;
-            if (attn_mode == COGS_ATTN_REF_EAGER_GLOBAL) { a.row_lo = lo; a.row_hi = hi; a.bias = 1.0f; }
-            else {
-                a.cu_seqlens = cu; a.nseg = nframes; a.max_seqlen = max_seq;
-                a.uniform_seqlen = uniform_seq;      // all frames alike (one video, or videos of one grid): see attn_vit.hip
-            }
-            { PROF(COGS_PROF_ATTN); COGS_TRY(cogs_k_attention(st, a)); }
-        }
-        {
-            CogsGemm g; g.dtype = dt;
-            g.A = att; g.lda = H; g.W = L.o_w; g.ldw = H; g.C = x; g.ldc = H;
-            g.bias = L.o_b; g.residual = x; g.ldr = H; g.M = (int)N; g.N = H; g.K = H;
-            if (fold) g.row_stats = stat_part;
-            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
-        }
-        if (fold) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_ln_finalize(st, stat_part, (int)N, H / 64, H, w.ln_eps, ln_ab)); }
-        else { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln2_g, L.ln2_b, (int)N, H, w.ln_eps)); }
-        {
-            CogsGemm g; g.dtype = dt;
-            g.A = fold ? x : ln; g.lda = H; g.W = L.fc1_w; g.ldw = H; g.C = big; g.ldc = w.inter_pad;
-            g.M = (int)N; g.N = w.inter_pad; g.K = H; g.act = COGS_ACT_GELU_TANH;
-            if (fold) { g.ln_ab = ln_ab; g.col_c = L.fc1_c; }
-            else g.bias = L.fc1_b;
-            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
-        }
-        {
-            CogsGemm g; g.dtype = dt;
-            g.A = big; g.lda = w.inter_pad; g.W = L.fc2_w; g.ldw = w.inter_pad; g.C = x; g.ldc = H;
-            g.bias = L.fc2_b; g.residual = x; g.ldr = H; g.M = (int)N; g.N = H; g.K = w.inter_pad;
-            if (fold && l + 1 < w.layers) g.row_stats = stat_part;     // the last layer feeds post_layernorm (own kernel)
-            { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
-        }
-    }
-    // post_layernorm + per-video 2x2 merge (:482-510)
+    head_major = prescale_q && hd == 72 && g_cogs_debug.gemm_headmajor != 0 && g_cogs_debug.attn_vit != 0 &&
+                 (double)N * H * 2.0 < 4294967296.0;
+    return COGS_OK;
+}
+
+cogs_status VitRange::layer(int l) {
+    const cogs_vit_weights& w = h->vit;
+    const int dt = w.dtype;
+    const size_t es = esize(dt);
+    const int H = w.hidden, hd = H / w.heads;
+    char* qkv = (char*)big;
+    char* att = qkv + (size_t)N * 3 * H * es;
+    const cogs_vit_layer& L = h->vit_layers[l];
+    if (fold) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_ln_finalize(st, stat_part, (int)N, H / 64, H, w.ln_eps, ln_ab)); }
+    else { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln1_g, L.ln1_b, (int)N, H, w.ln_eps)); }
     {
-        int64_t row = 0, orow = 0;
-        for (int v = 0; v < V; ++v) {
-            const int64_t n = grid_sizes[3 * v] * grid_sizes[3 * v + 1] * grid_sizes[3 * v + 2];
-            const int grp = (int)(merge_sizes[v] * merge_sizes[v]);
-            { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_ln_merge(st, dt, (char*)x + (size_t)row * H * es, (char*)out_tokens + (size_t)orow * H * es,
-                                     w.post_ln_g, w.post_ln_b, (int)(n / grp), grp, H, w.ln_eps)); }
-            row += n;
-            orow += n / grp;
+        CogsGemm g; g.dtype = dt;
+        g.A = fold ? x : ln; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.C = qkv; g.ldc = 3 * H;
+        g.M = (int)N; g.N = 3 * H; g.K = H;
+        if (fold) { g.ln_ab = ln_ab; g.col_c = L.qkv_c; }
+        else g.bias = L.qkv_b;
+        g.rope_cos = rc; g.rope_sin = rs; g.rope_cols = 2 * H; g.head_dim = hd;
+        if (prescale_q) { g.q_scale = scale * 1.4426950408889634f; g.q_cols = H; }
+        if (use_lut) { g.rope_lut = lut; g.rope_rowpos = lo; g.rope_maxpos = maxpos; }
+        if (head_major) { g.hm_rows = N; g.hm_cols = H; }
+        { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
+    }
+    {
+        CogsAttn a; a.dtype = dt;
+        a.Q = qkv; a.K = qkv + (size_t)H * es; a.V = qkv + (size_t)2 * H * es; a.O = att;
+        a.ldq = a.ldk = a.ldv = 3 * H; a.ldo = H;
+        if (head_major) {
+            a.K = qkv + (size_t)N * H * es; a.V = qkv + (size_t)2 * N * H * es;
+            a.ldq = a.ldk = a.ldv = hd; a.head_stride = (long)N * hd;
         }
+        a.q_len = (int)N; a.kv_len = (int)N; a.hq = a.hkv = w.heads; a.head_dim = hd; a.scale = scale;
+        a.q_prescaled = prescale_q;
+        if (attn_mode == COGS_ATTN_REF_EAGER_GLOBAL) { a.row_lo = lo; a.row_hi = hi; a.bias = 1.0f; }
+        else {
+            a.cu_seqlens = cu; a.nseg = nframes; a.max_seqlen = max_seq;
+            a.uniform_seqlen = uniform_seq;      // all frames alike (one video, or videos of one grid): see attn_vit.hip
+        }
+        { PROF(COGS_PROF_ATTN); COGS_TRY(cogs_k_attention(st, a)); }
+    }
+    {
+        CogsGemm g; g.dtype = dt;
+        g.A = att; g.lda = H; g.W = L.o_w; g.ldw = H; g.C = x; g.ldc = H;
+        g.bias = L.o_b; g.residual = x; g.ldr = H; g.M = (int)N; g.N = H; g.K = H;
+        if (fold) g.row_stats = stat_part;
+        { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
+    }
+    if (fold) { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_ln_finalize(st, stat_part, (int)N, H / 64, H, w.ln_eps, ln_ab)); }
+    else { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_layernorm(st, dt, x, ln, L.ln2_g, L.ln2_b, (int)N, H, w.ln_eps)); }
+    {
+        CogsGemm g; g.dtype = dt;
+        g.A = fold ? x : ln; g.lda = H; g.W = L.fc1_w; g.ldw = H; g.C = big; g.ldc = w.inter_pad;
+        g.M = (int)N; g.N = w.inter_pad; g.K = H; g.act = COGS_ACT_GELU_TANH;
+        if (fold) { g.ln_ab = ln_ab; g.col_c = L.fc1_c; }
+        else g.bias = L.fc1_b;
+        { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
+    }
+    {
+        CogsGemm g; g.dtype = dt;
+        g.A = big; g.lda = w.inter_pad; g.W = L.fc2_w; g.ldw = w.inter_pad; g.C = x; g.ldc = H;
+        g.bias = L.fc2_b; g.residual = x; g.ldr = H; g.M = (int)N; g.N = H; g.K = w.inter_pad;
+        if (fold && l + 1 < w.layers) g.row_stats = stat_part;     // the last layer feeds post_layernorm (own kernel)
+        { PROF(COGS_PROF_GEMM); COGS_TRY(cogs_k_gemm(st, g)); }
+    }
+    return COGS_OK;
+}
+
+// post_layernorm + per-video 2x2 merge (:482-510)
+cogs_status VitRange::finish() {
+    const cogs_vit_weights& w = h->vit;
+    const int dt = w.dtype;
+    const size_t es = esize(dt);
+    const int H = w.hidden;
+    int64_t row = 0, orow = 0;
+    for (int v = 0; v < V; ++v) {
+        const int64_t n = grid[3 * v] * grid[3 * v + 1] * grid[3 * v + 2];
+        const int grp = (int)(merge[v] * merge[v]);
+        { PROF(COGS_PROF_NORM); COGS_TRY(cogs_k_ln_merge(st, dt, (char*)x + (size_t)row * H * es, (char*)out_tokens + (size_t)orow * H * es,
+                                 w.post_ln_g, w.post_ln_b, (int)(n / grp), grp, H, w.ln_eps)); }
+        row += n;
+        orow += n / grp;
     }
     return COGS_OK;
 }

@@ -334,10 +334,11 @@ cogs_status cogs_vit_workspace_bytes(cogs_handle h, int64_t n_patches, size_t* b
 cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
                             const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
                             void* out_tokens, void* ws, size_t ws_bytes);
-/* cogs_vit_encode runs a clip of two or more frames as two halves on two streams (the caller's and one the handle owns;
- * frames are independent under per-frame attention, the tokens are bit-identical to a one-stream encode): the second
- * half's kernels fill the partly empty last rounds of the first half's persistent GEMM launches. streams = 1 keeps
- * everything on the caller's stream, 2 (the default) allows the split. */
+/* cogs_vit_encode runs a clip of two or more frames as `streams` contiguous frame ranges on as many streams (the caller's
+ * and up to three the handle owns; frames are independent under per-frame attention, the tokens are bit-identical to a
+ * one-stream encode): one range's kernels fill the partly empty last rounds of another's persistent GEMM launches. The
+ * ranges are queued layer by layer in turn, so every stream starts within one layer of the first. streams = 1 keeps
+ * everything on the caller's stream, 2 is the default, 3 and 4 are allowed. */
 cogs_status cogs_vit_set_streams(cogs_handle h, int streams);
 
 /* ----------------------------------------------------------------------- multi-GPU ------ */

@@ -35,6 +35,7 @@ vcfg = VisionConfig()
 enc = VisionEncoder(random_vit_state(vcfg, 0, dev, torch.bfloat16), vcfg, device=dev)
 proj = Projector(random_proj_state(1152, 3584, 1, dev, torch.bfloat16), device=dev)
 T = args.frames
+torch.manual_seed(0)
 pix = (torch.rand(T * gh * gw, 588, device=dev) * 2 - 1).to(torch.bfloat16)
 grid, merge = torch.tensor([[T, gh, gw]]), torch.tensor([2])
 variants = [("default", {})] + [(s, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in s.split(","))) for s in args.specs]
