@@ -65,6 +65,8 @@ __device__ __forceinline__ float colgroup_max(float x) {
 
 __device__ __forceinline__ int k_swz(int row) { return (row & 3) | (((row >> 3) & 3) << 2); }
 
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
 // NQ = 16-row query sub-tiles per wave: 2 -> 4 waves x 32 rows (256 threads, 2 waves per SIMD at 2 workgroups per CU);
 // 1 -> 8 waves x 16 rows (512 threads): half the accumulator / score registers per wave, so twice the waves per
 // SIMD overlap each other's MFMA, VALU and LDS phases, at the price of reading every K/V fragment for 16 rows only.
@@ -776,6 +778,354 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Qwen2 prompt attention with 64 query rows per wave (round 5): the construction of the encoder's pipelined kernel
+// (attn_vit.hip) at head dim 128. The kernel above reads every K / V fragment from LDS for 32 query rows -- 48 LDS reads
+// per 1 024 cycles of MFMA, each wave's softmax in front of its own PV product -- and sits at ~50 % of the matrix pipe
+// whatever the staging (register-staged, LDS-DMA, ping-pong: DESIGN.md 4.4). Here
+//   * a workgroup is 4 waves x 64 query rows = 256 rows of one (query head, sequence), ONE wave per SIMD with the whole
+//     512-register file: O^T 2 x 4 x 16 accumulators, Q fragments of both 32-row blocks (64), two score sets (64);
+//   * v_mfma_f32_32x32x16_bf16, S^T[key][q] = K.Q^T and O^T[d][q] += V^T[d][key].P^T[key][q] as in attn_vit.hip (the score
+//     accumulator registers of a lane ARE the B fragment of the PV product), every K and V^T fragment feeding the MFMAs
+//     of BOTH 32-row blocks: 24 LDS reads per 1 024 MFMA cycles;
+//   * software pipeline at 32-key blocks: sub-step j = {P(j) = exp2(S(j)), row sums} beside {S(j+1) = K(j+1).Q^T, 16
+//     MFMAs}, then {O += V(j)^T.P(j), 16 MFMAs} beside {max over S(j+1), K fragments of block j+2};
+//   * the reference maximum is the accumulators' initial value (-m: no per-score subtraction) and moves only when a
+//     block exceeds it by more than 2^6 (wave-uniform rare path: O and l rescaled, the pending scores shifted);
+//   * K / V tiles (64 keys x 256 B each) by LDS-DMA into a ring of four 32 KiB slots, three tiles ahead, one counted
+//     vmcnt + one barrier per tile; bank swizzles on the SOURCE side: K chunk ^= row & 15 (conflict-free ds_read_b128 over
+//     the 32 keys of an A fragment), V chunk ^= (row & 3) << 2 (the four rows a transposing read touches per half wave
+//     fall into four different 64-byte bank quarters);
+//   * causal / key-range masks only on the blocks that need them (the last five tiles of a workgroup at most).
+// STATUS (round 5): correct (tests/test_gpu_fullsize.py runs it at 15 395 tokens and in the 19-sequence form against fp32
+// torch), measured, OFF by default (debug switch attn_prefill64 = 1): 2.94 ms per layer against 1.97 ms for the kernel
+// above on the same box (tools/attn_prefill_ab.py). What the disassembly says: with one wave per SIMD the register file is
+// 256 vector + 256 accumulator registers and hipcc decides what lives where -- it keeps the Q fragments in vector
+// registers and both score sets in accumulator registers, so every 32-key block pays 32 v_accvgpr_write (the -m initial
+// values) and 32 v_accvgpr_read (scores back for the exponentials): ~2 300 vector-issue cycles per 64-key tile against
+// 2 048 of MFMA; and 30 spilled registers, 14 of them reloaded inside the tile loop -- scratch loads count on vmcnt, so
+// the compiler's wait for them (vmcnt(0)) drains the three-tile LDS-DMA prefetch in every sub-step, with no second wave
+// on the SIMD to cover it. Pinning Q or O to the accumulator half with "a"-constrained asm made the allocation worse (417
+// -- 602 spills); only the rare-path O rescale written through single v_accvgpr_read / write pairs helped (393 -> 30).
+// What it needs is the guide's form: O, Q (and the -m splat) in asm-owned accumulator ranges and the MFMAs issued from
+// inline asm with literal registers, the softmax alone in compiler-allocated vector registers.
+__global__ __launch_bounds__(256, 1) void attn_prefill64_kernel(AttnArgs p) {
+    constexpr int HD = 128, KS = 8, DB = 4, NQ = 2, NS = 4;
+    constexpr int RS = 256, TILE = 64 * RS, STAGE = 2 * TILE;            // 32 KiB per tile: [K | V]
+    constexpr float THR = 6.0f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // NS * STAGE = 128 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r32 = lane & 31;
+    const int seg = blockIdx.z, head = blockIdx.y;
+    const int kvh = head / (p.hq / p.hkv);
+    int qs = 0, qe = p.q_len, ks = 0, ke = p.kv_len;
+    if (p.cu) { qs = p.cu[seg]; qe = p.cu[seg + 1]; ks = qs; ke = qe; }
+    const int qt = p.heavy_first ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int q0 = qs + qt * 256;
+    if (q0 >= qe) return;
+    const int kend = min(ke, ks + (q0 - qs) + 255 + p.q_pos0 + 1);       // causal: nothing beyond the last row's diagonal
+    const int len = kend - ks;                                          // >= 1 (q_pos0 >= 0)
+    const int nt = (len + 63) >> 6, nblk = (len + 31) >> 5;
+    // blocks [0, nfree) need no mask for ANY row of the workgroup: wholly inside the key range and at or left of the
+    // first row's diagonal
+    int nfree = (q0 - qs) + p.q_pos0 - 31 >= 0 ? ((q0 - qs) + p.q_pos0 - 31) / 32 + 1 : 0;
+    nfree = min(nfree, min((ke - ks) >> 5, nblk));
+
+    const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q);
+    const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K);
+    const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.V);
+
+    // Q fragments (B operand of S^T = K.Q^T): lane (q = r32, h) holds Q[q][16 s + 8 h + 0..7] of both 32-row blocks
+    int qrow[NQ];
+    bool qok[NQ];
+    u32x4 qf[NQ][KS];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        qrow[qi] = q0 + wid * 64 + qi * 32 + r32;
+        qok[qi] = qrow[qi] < qe;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qf[qi][s] = u32x4{0, 0, 0, 0};
+            if (qok[qi]) qf[qi][s] = *reinterpret_cast<const u32x4*>(Qp + (long)qrow[qi] * p.ldq + head * HD + 16 * s + 8 * h);
+        }
+    }
+    const bool wave_active = q0 + wid * 64 < qe;
+
+    // ---- staging: a tile is 16 + 16 pieces of 1 KiB (4 rows x 256 B); wave w issues pieces w, w + 4, w + 8, w + 12 of K and V
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    int st_row[4], k_off[4], v_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * (wid + 4 * i) + (lane >> 4);
+        st_row[i] = row;
+        k_off[i] = (row * (int)p.ldk + kvh * HD + ((lane & 15) ^ (row & 15)) * 8) * 2;          // bytes from the tile's first row
+        v_off[i] = (row * (int)p.ldv + kvh * HD + ((lane & 15) ^ ((row & 3) << 2)) * 8) * 2;
+    }
+    auto uniform_ptr = [](const bf16_t* q) -> const bf16_t* {
+        const unsigned long long v = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const bf16_t*)(((unsigned long long)hi << 32) | lo);
+    };
+    auto dma16 = [&](const bf16_t* base, int off_bytes, unsigned lds) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(lds), "v"(off_bytes), "s"(base) : "memory");
+    };
+    const bf16_t* k_next = Kp + (long)ks * p.ldk;
+    const bf16_t* v_next = Vp + (long)ks * p.ldv;
+    const long k_step = 64 * p.ldk, v_step = 64 * p.ldv;
+    auto issue_tile = [&](int t) {                                       // tiles are issued strictly in order
+        const int valid = ke - (ks + t * 64);                            // >= 1
+        const bf16_t* kb = uniform_ptr(k_next);
+        const bf16_t* vb = uniform_ptr(v_next);
+        k_next += k_step; v_next += v_step;
+        const unsigned st = __builtin_amdgcn_readfirstlane(smem_lds + (t & (NS - 1)) * STAGE);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ko = k_off[i], vo = v_off[i];
+            if (valid < 64) {                                            // rows past the key range repeat its last row
+                const int back = st_row[i] - min(st_row[i], valid - 1);
+                ko -= back * (int)p.ldk * 2;
+                vo -= back * (int)p.ldv * 2;
+            }
+            dma16(kb, ko, st + (wid + 4 * i) * 1024);
+            dma16(vb, vo, st + TILE + (wid + 4 * i) * 1024);
+        }
+    };
+    auto wait_tiles = [&](int newer) {                                   // all but the `newer` newest tiles of this wave landed
+        if (newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    };
+
+    // ---- per-lane LDS read offsets inside a stage
+    // K fragment of k-step s: lane (key r32, h) reads logical chunk 2 s + h of row 32 kb + r32, stored at chunk ^ (row & 15)
+    int kx[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kx[s] = r32 * RS + (((2 * s + h) ^ (r32 & 15)) << 4);
+    // V^T fragment: lane supplies the 8-byte piece (key 4 h + q4 [+ 8], d = 32 b + 16 ((lane >> 4) & 1) + 4 (lane & 3) .. + 3);
+    // logical chunk 4 b + 2 ((lane >> 4) & 1) + ((lane & 3) >> 1), stored at chunk ^ (q4 << 2)
+    const int q4 = (lane & 15) >> 2;
+    int vx[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+        vx[b] = TILE + (4 * h + q4) * RS + (((4 * (b ^ q4)) + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) << 4) + 8 * (lane & 1);
+
+    f32x16 oacc[NQ][DB];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qi][b][r] = 0.f;
+    float sh[NQ] = {0.f, 0.f}, l_run[NQ] = {0.f, 0.f};
+
+    auto stage = [&](int t) -> const char* { return smem + (t & (NS - 1)) * STAGE; };
+    auto read_k = [&](const char* st, int kb, u32x4 (&kf)[KS]) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const u32x4*>(st + kx[s] + kb * 32 * RS);
+    };
+    auto read_v = [&](const char* st, int b, int kb, int s2) -> u32x4 {
+        const char* a0 = st + vx[b] + (32 * kb + 16 * s2) * RS;
+        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(a0));
+        const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(a0 + 8 * RS));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        return u32x4{l2[0], l2[1], h2[0], h2[1]};
+    };
+    auto qk_blk = [&](const u32x4 (&kf)[KS], f32x16& sx, const int qi) {           // S - m of one (key block, row block)
+        f32x16 c0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[r] = -sh[qi];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[s]), __builtin_bit_cast(bf16x8, qf[qi][s]),
+                                                         s == 0 ? c0 : sx, 0, 0, 0);
+    };
+    auto mask_blk = [&](f32x16& sx, const int jb, const int qi) {                   // keys outside the range / right of the diagonal
+        const int lim = min(ke - ks - 1, (qrow[qi] - qs) + p.q_pos0);               // last visible key of this lane's row, relative
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * jb + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (key > lim) sx[r] = -INFINITY;
+        }
+    };
+    auto own_max = [&](const f32x16& sx) -> float {
+        float d = sx[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) d = fmaxf(d, sx[r]);
+        return d;
+    };
+    auto pair_max = [&](float d) -> float {
+        const unsigned db = __builtin_bit_cast(unsigned, d);
+        const auto sw = __builtin_amdgcn_permlane32_swap(db, db, false, false);
+        return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    };
+
+    // ---- prologue
+    issue_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[qi][s]));          // Q loads complete before the loop
+    __builtin_amdgcn_s_barrier();
+    if (nt > 1) issue_tile(1);
+    if (nt > 2) issue_tile(2);
+
+    f32x16 sa[NQ], sb[NQ];
+    u32x4 kf[KS];                                                                  // K fragments of the NEXT block to be multiplied
+    if (wave_active) {
+        read_k(stage(0), 0, kf);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            qk_blk(kf, sa[qi], qi);                                                // shift 0
+            if (nfree == 0) mask_blk(sa[qi], 0, qi);
+            float d = pair_max(own_max(sa[qi]));
+            if (!(d > -INFINITY)) d = 0.f;                                         // a row that sees no key of block 0 (never: key 0 is visible)
+            sh[qi] = d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[qi][r] -= d;
+        }
+        read_k(stage(0), 1, kf);
+    }
+
+    // sub-step j: consumes sc = S(j) - m, produces sn = S(j+1) - m from kf, leaves the fragments of block j+2 in kf.
+    // KIND 1: block j+1 needs no mask; 2: it does; 0: j is the last block
+    auto substep = [&](f32x16 (&sc)[NQ], f32x16 (&sn)[NQ], const int j, auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        const char* st_c = stage(j >> 1);
+        u32x4 vf[DB][2];
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) vf[b][s2] = read_v(st_c, b, j & 1, s2);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 1: S(j+1) beside P(j)
+        if constexpr (KIND != 0) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) qk_blk(kf, sn[qi], qi);
+        }
+        u32x4 pf[NQ][2];
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            float psum = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float p0 = __builtin_amdgcn_exp2f(sc[qi][8 * s2 + 2 * w]), p1 = __builtin_amdgcn_exp2f(sc[qi][8 * s2 + 2 * w + 1]);
+                    psum += p0 + p1;
+                    pf[qi][s2][w] = pack_bf2(p0, p1);
+                }
+            l_run[qi] += psum;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2: O += V(j)^T.P(j) beside the maximum of S(j+1) and the K fragments of block j+2
+        if constexpr (KIND != 0) read_k(stage((j + 2) >> 1), (j + 2) & 1, kf);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi)
+                    oacc[qi][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[b][s2]),
+                                                                        __builtin_bit_cast(bf16x8, pf[qi][s2]), oacc[qi][b], 0, 0, 0);
+        if constexpr (KIND != 0) {
+            if constexpr (KIND == 2) {
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) mask_blk(sn[qi], j + 1, qi);
+            }
+            const float d0 = own_max(sn[0]), d1 = own_max(sn[1]);
+            if (__builtin_expect(__any(fmaxf(d0, d1) > THR), 0)) {
+                // rare (wave-uniform): move the reference of the rows that need it; O and l, complete up to block j, are
+                // multiplied by 2^-(m_new - m), the pending scores shifted by the same amount
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the PV MFMAs' results, read below by inline asm hipcc does not pad for
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    const float d = pair_max(qi == 0 ? d0 : d1);
+                    const float up = d > THR ? d : 0.f;
+                    const float al = __builtin_amdgcn_exp2f(-up);
+                    sh[qi] += up;
+                    l_run[qi] *= al;
+                    // O lives in the accumulator half of the register file (one wave per SIMD: 256 + 256 registers). Written as
+                    // plain C++ (oacc *= al) this rare branch made hipcc keep O where vector instructions reach it and spill
+                    // 393 registers in the whole kernel; element by element through ONE temporary it spills 30, none in the loop
+#pragma unroll
+                    for (int b = 0; b < DB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float tmp;
+                            asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 1\n\tv_mul_f32 %1, %1, %2\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1\n\ts_nop 1"
+                                         : "+a"(oacc[qi][b][r]), "=&v"(tmp) : "v"(al));
+                        }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sn[qi][r] -= up;
+                }
+            }
+        }
+    };
+    auto tile_head = [&](const int t) {
+        wait_tiles(t + 2 < nt ? 1 : 0);       // outstanding, oldest first: tile t+1, tile t+2; tile t+1 must have landed
+        __builtin_amdgcn_s_barrier();         // K(t+1), V(t) visible to all; slot of tile t-1 no longer read by anyone
+        if (t + 3 < nt) issue_tile(t + 3);
+    };
+    using Free = std::integral_constant<int, 1>;
+    using Masked = std::integral_constant<int, 2>;
+    using Last = std::integral_constant<int, 0>;
+    int t = 0;
+    for (; 2 * t + 2 < nfree; ++t) {          // blocks 2t+1 and 2t+2 need no mask
+        tile_head(t);
+        if (wave_active) {
+            substep(sa, sb, 2 * t, Free{});
+            substep(sb, sa, 2 * t + 1, Free{});
+        }
+    }
+    for (; t < nt; ++t) {                     // the masked end: block kinds decided at run time (wave-uniform)
+        tile_head(t);
+        if (!wave_active) continue;
+        {
+            const int j = 2 * t;
+            if (j + 1 < nfree) substep(sa, sb, j, Free{});
+            else if (j + 1 < nblk) substep(sa, sb, j, Masked{});
+            else substep(sa, sb, j, Last{});
+        }
+        if (2 * t + 1 < nblk) {
+            const int j = 2 * t + 1;
+            if (j + 1 < nfree) substep(sb, sa, j, Free{});
+            else if (j + 1 < nblk) substep(sb, sa, j, Masked{});
+            else substep(sb, sa, j, Last{});
+        }
+    }
+    if (!wave_active) return;
+
+    // epilogue: lane (q, h) holds d = 32 b + 8 g4 + 4 h + 0..3; pack and exchange between the halves so that a lane owns 8
+    // consecutive d (attn_vit.hip)
+    bf16_t* Op = reinterpret_cast<bf16_t*>(p.O);
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        float l = l_run[qi];
+        l += __shfl_xor(l, 32, 64);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        bf16_t* orow = Op + (long)qrow[qi] * p.ldo + head * HD;
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                unsigned e0 = pack_bf2(oacc[qi][b][8 * gp + 0] * inv, oacc[qi][b][8 * gp + 1] * inv);
+                unsigned e1 = pack_bf2(oacc[qi][b][8 * gp + 2] * inv, oacc[qi][b][8 * gp + 3] * inv);
+                unsigned o0 = pack_bf2(oacc[qi][b][8 * gp + 4] * inv, oacc[qi][b][8 * gp + 5] * inv);
+                unsigned o1 = pack_bf2(oacc[qi][b][8 * gp + 6] * inv, oacc[qi][b][8 * gp + 7] * inv);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+                const int d0 = 32 * b + 16 * gp + 8 * h;
+                if (qok[qi]) *reinterpret_cast<u32x4*>(orow + d0) = u32x4{(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Ping-pong form of the prompt attention above (round 4): 8 waves = 256 query rows of one head per workgroup, two
 // groups of four waves, one wave of each group per SIMD. In the kernel above the two waves of a SIMD belong to different
 // workgroups and fall into step: per tile a SIMD spends the SUM of a wave's 1 024 MFMA cycles and its ~900 cycles of
@@ -1396,7 +1746,12 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
             // 1 024 cycles of MFMA, because every K / V fragment read from LDS feeds only two MFMAs (32 query rows per
             // wave): 48 LDS reads per 64 MFMAs. Off by default; debug switch attn_prefill_pp = 1 selects it.
             const bool env_pp = g_cogs_debug.attn_prefill_pp == 1;
-            if (env_pp && max_len >= 256) {
+            if (g_cogs_debug.attn_prefill64 && max_len >= 256) {
+                static std::atomic<uint64_t> attr_done64{0};
+                cogs_ensure_dyn_lds((const void*)attn_prefill64_kernel, 4 * 32 * 1024, attr_done64);
+                g_cogs_debug.attn_last_kernel = 9;
+                hipLaunchKernelGGL(attn_prefill64_kernel, dim3((max_len + 255) / 256, gy, nseg), dim3(256), 4 * 32 * 1024, st, p);
+            } else if (env_pp && max_len >= 256) {
                 static std::atomic<uint64_t> attr_done{0};
                 cogs_ensure_dyn_lds((const void*)attn_prefill_pp_kernel, 5 * 32 * 1024, attr_done);
 #ifdef COGS_ATTN_PP_STAMPS

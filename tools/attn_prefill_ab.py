@@ -38,9 +38,9 @@ times = {name: [] for name, _ in variants}
 sums = {}
 for rnd in range(7):                      # interleaved rounds: every variant sees the same device state
     for name, sw in variants:
-        olds = {k: L.debug_get(k) for k in sw}
-        for k, v_ in sw.items():
-            L.debug_set(k, v_)
+        olds = {name_: L.debug_get(name_) for name_ in sw}
+        for name_, val_ in sw.items():
+            L.debug_set(name_, val_)
         o = run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -49,8 +49,8 @@ for rnd in range(7):                      # interleaved rounds: every variant se
         torch.cuda.synchronize()
         times[name].append((time.perf_counter() - t0) / 5)
         sums[name] = float(o.float().abs().sum())
-        for k, v_ in olds.items():
-            L.debug_set(k, v_)
+        for name_, val_ in olds.items():
+            L.debug_set(name_, val_)
 for name, _ in variants:
     t = sorted(times[name])[len(times[name]) // 2]
     print(f"S={S} variant={name}: median {t * 1e3:.3f} ms (min {min(times[name]) * 1e3:.3f}), {fl / t / 1e12:.0f} TFLOP/s, "
