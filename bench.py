@@ -671,7 +671,7 @@ def main() -> None:
         # passes: FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction). The figure is read from the
         # PMC summary of the same command committed under profiles/ (tools/collect_profiles.sh), and labelled so.
         traffic, traffic_src = None, None
-        for name in ("r4_gemm_traffic.json", "r3_gemm_traffic.json", "r2_gemm_traffic.json", "r1_g_gemm_traffic.json"):
+        for name in ("r5_gemm_traffic.json", "r4_gemm_traffic.json", "r3_gemm_traffic.json", "r2_gemm_traffic.json", "r1_g_gemm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if world == 1 and T == 64 and not cfg3 and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")

@@ -187,7 +187,7 @@ class Qwen2Engine:
         seen = torch.empty(n_prompt + max_new_tokens, dtype=torch.int64, device=self.device)
         if n_prompt:
             seen[:n_prompt] = prompt_ids.reshape(-1).to(self.device)
-        toks = torch.empty(max_new_tokens, dtype=torch.int64, device=self.device)
+        toks = seen[n_prompt:]        # the generated ids ARE the tail of the penalty history: argmax / the sampler write them once
         n_seen, produced = n_prompt, 0
         # host-drawn sampling (parity mode) consumes one [vocab] draw of the CPU generator per step: steps issued past
         # the EOS would advance that generator beyond where GenerationMixin stops, so the stop test runs every step
@@ -207,8 +207,6 @@ class Qwen2Engine:
                                      seed=seed or 0, offset=step, temperature=temperature, out=toks[step:step + 1])
             else:
                 tok_dev = ops.argmax(logits, out=toks[step:step + 1])      # straight into the generated-ids buffer
-            if repetition_penalty != 1.0:                                  # the penalty history (nothing else reads it)
-                seen[n_seen:n_seen + 1].copy_(tok_dev)
             n_seen += 1
             produced += 1
             last = step + 1 == max_new_tokens

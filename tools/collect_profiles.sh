@@ -10,7 +10,7 @@
 #   5. SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE (matrix-pipe busy share per kernel)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r4}
+TAG=${1:-r5}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
