@@ -163,6 +163,29 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float t = x * fmaf(b, x * x, a);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
+// the same on four values in packed fp32 arithmetic: 2 x (v_pk_mul, v_pk_fma, v_pk_mul, v_pk_add, v_pk_mul) + 4 v_exp + 4 v_rcp
+// instead of 4 x 5 scalar VALU + the same transcendentals. Written on vectors because hipcc's SLP pass only packs about half of
+// the scalar form inside the GEMM epilogues, and every VALU instruction there is taken from the matrix pipe
+// (profiles/r5_prefill_attn_anatomy.txt section 4: ~2 cycles per instruction beside 16x16x32 MFMAs; v_exp / v_rcp run beside it).
+// Bit-identical to gelu_tanh_f per element (same operations in the same order).
+__device__ __forceinline__ f32x4 gelu_tanh_4(f32x4 x) {
+    const float a = -2.3022082f, b = -0.10294324f;
+    const f32x4 a4 = {a, a, a, a}, b4 = {b, b, b, b}, one = {1.f, 1.f, 1.f, 1.f};
+#ifdef COGS_EPI_SCALAR_MATH      // A/B builds (tools/build_alt.sh gemm -DCOGS_EPI_SCALAR_MATH): the scalar form of rounds 1-4
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f(x[e]);
+    return y;
+#endif
+    const f32x4 t = x * __builtin_elementwise_fma(b4, x * x, a4);
+    f32x4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_exp2f(t[e]);
+    d += one;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_rcpf(d[e]);
+    return x * d;
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
 }

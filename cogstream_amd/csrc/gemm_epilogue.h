@@ -128,8 +128,7 @@ __device__ __forceinline__ void epilogue4(const EpiArgs& p, int m, int n, f32x4 
     }
     if (n < p.q_cols) v *= p.q_scale;
     if (p.act == COGS_ACT_GELU_TANH) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+        v = gelu_tanh_4(v);
     } else if (p.act == COGS_ACT_GELU_ERF) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
@@ -272,8 +271,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiArgs& p, int mb, int nb, 
                         if (n < p.q_cols) v[ni] *= p.q_scale;
                     }
                     if constexpr ((EPI & EPI_GELU_TANH) != 0) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[ni][e] = gelu_tanh_f(v[ni][e]);
+                        v[ni] = gelu_tanh_4(v[ni]);
                     }
                     if constexpr ((EPI & EPI_GELU_ERF) != 0) {
 #pragma unroll
@@ -443,8 +441,7 @@ __device__ __forceinline__ void epilogue_tile_fast(const EpiArgs& p, int mb, int
                     if (q_tile) v[ni] *= p.q_scale;
                 }
                 if constexpr ((EPI & EPI_GELU_TANH) != 0) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[ni][e] = gelu_tanh_f(v[ni][e]);
+                    v[ni] = gelu_tanh_4(v[ni]);
                 }
                 if constexpr ((EPI & EPI_GELU_ERF) != 0) {
 #pragma unroll
@@ -605,7 +602,7 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
     constexpr int NB = 16 / UPB;
     u32x4 res_wide[NB][UPB];
     f32x4 cs4[NB][UPB][2];
-    float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};   // EPI_ROWSTAT: running sums of the batch's (<= 2) row blocks
+    f32x4 st_sum[2], st_sq[2];                               // EPI_ROWSTAT: running (packed) sums of the batch's (<= 2) row blocks
     auto load_batch = [&](const int b) {
 #pragma unroll
         for (int j = 0; j < UPB; ++j) {
@@ -643,8 +640,12 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
                 v[h2] = (blk < 4) ? acc0[mi][ni] : acc1[mi][ni];
                 if constexpr ((EPI & EPI_LNFOLD) != 0) {
                     const float rs = rs_ring[UPB == 1 ? (blk & 1) : blk];
+#ifdef COGS_EPI_SCALAR_MATH
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[h2][e] = fmaf(rs, v[h2][e], bias_v[ni][e]);
+#else
+                    v[h2] = __builtin_elementwise_fma(f32x4{rs, rs, rs, rs}, v[h2], bias_v[ni]);
+#endif
                 } else if constexpr ((EPI & EPI_BIAS) != 0) v[h2] += bias_v[ni];
                 if constexpr ((EPI & EPI_ROPE) != 0) {
                     const f32x4 t = cs4[b][j][h2];   // c0 s0 c1 s1
@@ -652,8 +653,7 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
                     if (q_tile) v[h2] *= p.q_scale;
                 }
                 if constexpr ((EPI & EPI_GELU_TANH) != 0) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[h2][e] = gelu_tanh_f(v[h2][e]);
+                    v[h2] = gelu_tanh_4(v[h2]);
                 }
                 if constexpr ((EPI & EPI_GELU_ERF) != 0) {
 #pragma unroll
@@ -675,14 +675,21 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
                 // 4b..4b+3 = row blocks 2b, 2b+1, two units each)
                 const f32x4 ra = {bf_lo(a0), bf_hi(a0), bf_lo(a1), bf_hi(a1)};
                 const f32x4 rb = {bf_lo(b0), bf_hi(b0), bf_lo(b1), bf_hi(b1)};
+                // packed: 2 v_pk_add + 4 v_pk_fma/v_pk_mul + 3 adds per 8 values (the scalar chain was 8 v_add + 8 v_fma)
+#ifdef COGS_EPI_SCALAR_MATH
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     s1 += ra[e] + rb[e];
                     s2 = fmaf(ra[e], ra[e], fmaf(rb[e], rb[e], s2));
                 }
-                if ((j & 1) == 0) { st_sum[j >> 1] = s1; st_sq[j >> 1] = s2; }
-                else { st_sum[j >> 1] += s1; st_sq[j >> 1] += s2; }
+                const f32x4 sv = {s1, 0.f, 0.f, 0.f}, qv = {s2, 0.f, 0.f, 0.f};
+#else
+                const f32x4 sv = ra + rb;
+                const f32x4 qv = __builtin_elementwise_fma(ra, ra, rb * rb);
+#endif
+                if ((j & 1) == 0) { st_sum[j >> 1] = sv; st_sq[j >> 1] = qv; }
+                else { st_sum[j >> 1] += sv; st_sq[j >> 1] += qv; }
             }
             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
             const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
@@ -700,7 +707,8 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
             static_assert((EPI & EPI_ROWSTAT) == 0 || UPB == 4, "row statistics are laid out for 4-unit batches");
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const float t1 = rowgroup_sum(st_sum[k]), t2 = rowgroup_sum(st_sq[k]);
+                const float t1 = rowgroup_sum((st_sum[k][0] + st_sum[k][2]) + (st_sum[k][1] + st_sum[k][3]));
+                const float t2 = rowgroup_sum((st_sq[k][0] + st_sq[k][2]) + (st_sq[k][1] + st_sq[k][3]));
                 // all four lanes of a row hold the totals; ONE of them writes (8 bytes per row and wave tile). The store
                 // is issued by every lane with the other three pointed at the same address and value: no exec masking,
                 // so the instruction count the relaxed vmcnt relies on stays fixed (2 per batch, 8 per epilogue)
