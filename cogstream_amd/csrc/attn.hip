@@ -2100,8 +2100,10 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
         // the generated tokens' attention (one query row, key-split) has its own kernel: every wave owns whole tiles
         const bool env_old_dec = g_cogs_debug.attn_decode == 0;   // A/B runs only
         const bool env_no_dma = g_cogs_debug.attn_prefill_dma == 0;   // A/B runs only
-        if (a.head_dim == 128 && pre && a.causal && p.nsplit == 1 && !p.gqa_pack && !a.row_lo && !env_no_dma && a.q_len >= 128 &&
-            a.ldo % 8 == 0) {
+        // (every causal pre-scaled hd-128 call, whatever its length: a prompt continued behind a cached prefix with fewer than 128
+        // new rows must run the same per-row arithmetic as the full prompt -- PrefixKV's transparency, tests/test_gpu_models.py --
+        // and since round 5 this kernel's running maximum is no longer the general kernel's)
+        if (a.head_dim == 128 && pre && a.causal && p.nsplit == 1 && !p.gqa_pack && !a.row_lo && !env_no_dma && a.ldo % 8 == 0) {
             // the ping-pong form (attn_prefill_pp_kernel) is built, bit-identical and measured: 1.89 ms against 1.81-1.86 ms
             // per layer at 15 395 tokens on the same box -- both kernels sit at ~2 000 shader cycles per wave and tile for
             // 1 024 cycles of MFMA, because every K / V fragment read from LDS feeds only two MFMAs (32 query rows per

@@ -602,7 +602,7 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
     constexpr int NB = 16 / UPB;
     u32x4 res_wide[NB][UPB];
     f32x4 cs4[NB][UPB][2];
-    f32x4 st_sum[2], st_sq[2];                               // EPI_ROWSTAT: running (packed) sums of the batch's (<= 2) row blocks
+    float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};   // EPI_ROWSTAT: running sums of the batch's (<= 2) row blocks
     auto load_batch = [&](const int b) {
 #pragma unroll
         for (int j = 0; j < UPB; ++j) {
@@ -675,21 +675,16 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
                 // 4b..4b+3 = row blocks 2b, 2b+1, two units each)
                 const f32x4 ra = {bf_lo(a0), bf_hi(a0), bf_lo(a1), bf_hi(a1)};
                 const f32x4 rb = {bf_lo(b0), bf_hi(b0), bf_lo(b1), bf_hi(b1)};
-                // packed: 2 v_pk_add + 4 v_pk_fma/v_pk_mul + 3 adds per 8 values (the scalar chain was 8 v_add + 8 v_fma)
-#ifdef COGS_EPI_SCALAR_MATH
+                // (one association everywhere: a packed form of these sums was tried in round 5 -- no faster, and the generic
+                // epilogues of ragged tiles must produce the same bits for the frame-shard identity)
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     s1 += ra[e] + rb[e];
                     s2 = fmaf(ra[e], ra[e], fmaf(rb[e], rb[e], s2));
                 }
-                const f32x4 sv = {s1, 0.f, 0.f, 0.f}, qv = {s2, 0.f, 0.f, 0.f};
-#else
-                const f32x4 sv = ra + rb;
-                const f32x4 qv = __builtin_elementwise_fma(ra, ra, rb * rb);
-#endif
-                if ((j & 1) == 0) { st_sum[j >> 1] = sv; st_sq[j >> 1] = qv; }
-                else { st_sum[j >> 1] += sv; st_sq[j >> 1] += qv; }
+                if ((j & 1) == 0) { st_sum[j >> 1] = s1; st_sq[j >> 1] = s2; }
+                else { st_sum[j >> 1] += s1; st_sq[j >> 1] += s2; }
             }
             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
             const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
@@ -707,8 +702,7 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
             static_assert((EPI & EPI_ROWSTAT) == 0 || UPB == 4, "row statistics are laid out for 4-unit batches");
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const float t1 = rowgroup_sum((st_sum[k][0] + st_sum[k][2]) + (st_sum[k][1] + st_sum[k][3]));
-                const float t2 = rowgroup_sum((st_sq[k][0] + st_sq[k][2]) + (st_sq[k][1] + st_sq[k][3]));
+                const float t1 = rowgroup_sum(st_sum[k]), t2 = rowgroup_sum(st_sq[k]);
                 // all four lanes of a row hold the totals; ONE of them writes (8 bytes per row and wave tile). The store
                 // is issued by every lane with the other three pointed at the same address and value: no exec masking,
                 // so the instruction count the relaxed vmcnt relies on stays fixed (2 per batch, 8 per epilogue)
