@@ -31,8 +31,8 @@
     X(attn_decode, 1, "0: single-token attention through the general split-KV kernel")                                      \
     X(attn_combine32, 1, "split-KV combine: 1 one block per (head, 32-column slice), 8 loads in flight per thread; 0 one block per head") \
     X(attn_prefill_dma, 1, "0: Qwen2 prompt attention through the general register-staged kernel")                          \
-    X(attn_prefill_deep, 1, "prompt LDS-DMA kernel: 1 fragment reads ordered by hand 6-8 reads ahead of their MFMAs, 0 hipcc's order") \
-    X(attn_prefill_sp, 0, "1: Qwen2 prompt attention software-pipelined across key tiles (S(t+1) beside softmax(t), round 5); 0: attn_prefill_dma_kernel") \
+    X(attn_prefill_deep, 1, "prompt LDS-DMA kernel: 1 fragment reads ordered 6-8 ahead of their MFMAs + running maximum deferred to 2^6 (round 5: 1.82 -> 1.64 ms), 0 the round-4 kernel") \
+    X(attn_prefill_sp, 0, "1: Qwen2 prompt attention software-pipelined across key tiles (S(t+1) beside softmax(t); round 5: correct, measured 2.15 vs 1.64 ms -- off)") \
     X(attn_prefill64, 0, "1: Qwen2 prompt attention with 64 query rows per wave, software-pipelined (round 5: correct, measured 2.94 vs 1.97 ms per layer -- off)") \
     X(attn_prefill_pp, 0, "1: ping-pong form of the prompt attention (bit-identical, measured slower)")                     \
     X(attn_prio, 2, "prompt attention wave priorities: 0 none, 1 MFMA phases raised, 2 softmax phase raised")               \
