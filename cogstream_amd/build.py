@@ -196,7 +196,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not m0_stamp2.exists() or m0_stamp2.stat().st_mtime < attn2_o.stat().st_mtime:
         try:
             m0_bad = (check_m0_uses(attn2_o, "attn_prefill_dma_kernel") + check_m0_uses(attn2_o, "attn_prefill_pp_kernel") +
-                      check_m0_uses(attn2_o, "attn_prefill64_kernel") + check_m0_uses(attn2_o, "attn_prefill_sp_kernel"))
+                      check_m0_uses(attn2_o, "attn_prefill64_kernel"))
         except (OSError, RuntimeError) as e:
             if strict:
                 raise

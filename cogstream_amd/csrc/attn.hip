@@ -792,6 +792,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
         first_tile = false;
     };
 
+
+    // (Round 5 also built this loop with interior tiles as two 32-key halves pipelined INSIDE the tile -- S(h1) beside softmax(h0),
+    // PV(h0) beside softmax(h1), pinned by sched_group_barrier -- and, as attn_prefill_sp_kernel, with S(t+1) beside softmax(t)
+    // across tiles. Both correct at full size; 1.696 and 2.15 ms against 1.680 / 1.64: the matrix pipe and the VALU do not
+    // overlap in this kernel whatever the order. Measurements and per-block stamps: profiles/r5_prefill_attn_anatomy.txt.)
+
     // leading tiles [0, t_mid) need no mask: fully inside the key range and left of the causal diagonal
     int t_mid;
     {
@@ -830,296 +836,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
         if (kt + 1 < nt) issue_tile(kt + 1);
         process_tile(kt, std::true_type{});
         tile_tail(kt);
-    }
-
-    bf16_t* Op = reinterpret_cast<bf16_t*>(p.O);
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-        float l = l_run[qi];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        if (!qok[qi]) continue;
-        const float inv = l > 0.f ? 1.0f / l : 0.f;
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-            f32x4 v = oacc[d][qi] * inv;
-            st4_f<bf16_t>(Op + (long)qrow[qi] * p.ldo + blockIdx.y * HD + 16 * d + 4 * g, v);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The prompt kernel above, software-pipelined across key tiles (round 5). There a wave runs QK^T(t) -> softmax(t) ->
-// PV(t) strictly one after the other, and the two waves that share a SIMD (they belong to different workgroups) add up:
-// 2 x (1 024 MFMA cycles + ~650 of softmax issue + ~400 of LDS fragment reads) = the ~4 100 cycles per pair of wave-tiles
-// that both that kernel and its ping-pong form measure -- the matrix pipe is busy half the time. Here the scores of tile
-// t+1 are computed BESIDE the softmax of tile t, in one basic block, so that hipcc interleaves the 32 MFMAs with the
-// exponentials (as it does in attn_vit_pipe_kernel):
-//     iteration t:   S(t+1) = K(t+1).Q^T - m      beside      P(t) = exp2(S(t)), row sums, packing
-//                    O += V(t)^T.P(t)
-//                    rows whose maximum moved: O, l *= 2^-d, and the pending S(t+1) -= d
-// Same data movement, fragment layouts and arithmetic per element as the kernel above; what changes is the order of
-// the MFMAs in time, one more score set in registers (32), and the K ring: K must be ONE tile further ahead than V, so the
-// LDS holds three K tiles and two V tiles (80 KiB: two workgroups still fill a CU's 160 KiB). The first tile's
-// reference maximum is taken in the prologue, so the loop carries no first-tile case.
-__global__ __launch_bounds__(256, 2) void attn_prefill_sp_kernel(AttnArgs p) {
-    constexpr int HD = 128, NQ = 2, KS = 4, DT = 8;
-    constexpr int K_LDS = 64 * 256, V_LDS = 64 * 256, NK = 3;
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // NK * K_LDS + 2 * V_LDS = 80 KiB
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, li = lane & 15;
-    const int seg = blockIdx.z;
-    const int gsz = p.hq / p.hkv;
-    const int kvh = blockIdx.y / gsz;
-
-    int qs = 0, qe = p.q_len, ks = 0, ke = p.kv_len;
-    if (p.cu) { qs = p.cu[seg]; qe = p.cu[seg + 1]; ks = qs; ke = qe; }
-    const int qt = p.heavy_first ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
-    const int q0 = qs + qt * 128;
-    if (q0 >= qe) return;
-
-    const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q);
-    const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K);
-    const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.V);
-
-    bf16x8 qf[NQ][KS];
-    int qrow[NQ];
-    bool qok[NQ];
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-        qrow[qi] = q0 + wid * 32 + qi * 16 + li;
-        qok[qi] = qrow[qi] < qe;
-#pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) {
-            u32x4 v = {0, 0, 0, 0};
-            if (qok[qi]) v = *reinterpret_cast<const u32x4*>(Qp + (long)qrow[qi] * p.ldq + blockIdx.y * HD + 32 * s2 + 8 * g);
-            qf[qi][s2] = __builtin_bit_cast(bf16x8, v);
-        }
-    }
-    const int kend = min(ke, ks + (q0 - qs) + 127 + p.q_pos0 + 1);      // causal
-    const int nt = (kend - ks + 63) / 64;
-
-    f32x4 oacc[DT][NQ];
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) oacc[d][qi] = f32x4{0, 0, 0, 0};
-    float l_run[NQ] = {0.f, 0.f}, m_ref[NQ] = {0.f, 0.f};
-
-    // ---- staging by LDS-DMA: wave w issues pieces w, w + 4, w + 8, w + 12 (4 tile rows each) of a K or a V tile
-    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    int st_row[4], k_off[4], v_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 4 * (wid + 4 * i) + (lane >> 4);
-        st_row[i] = row;
-        k_off[i] = (row * (int)p.ldk + kvh * HD + ((lane & 15) ^ k_swz(row)) * 8) * 2;
-        v_off[i] = (row * (int)p.ldv + kvh * HD + ((lane & 15) ^ v_swz(row)) * 8) * 2;
-    }
-    auto uniform_ptr = [](const bf16_t* q) -> const bf16_t* {
-        const unsigned long long v = (unsigned long long)q;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return (const bf16_t*)(((unsigned long long)hi << 32) | lo);
-    };
-    auto dma16 = [&](const bf16_t* base, int off_bytes, unsigned lds) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :: "s"(lds), "v"(off_bytes), "s"(base) : "memory");
-    };
-    auto issue_k = [&](int kt) {
-        const int kbase = ks + kt * 64;
-        const int valid = ke - kbase;                               // >= 1
-        const bf16_t* kb = uniform_ptr(Kp + (long)kbase * p.ldk);
-        const unsigned st = __builtin_amdgcn_readfirstlane(smem_lds + (kt % NK) * K_LDS);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int ko = k_off[i];
-            if (valid < 64) ko -= (st_row[i] - min(st_row[i], valid - 1)) * (int)p.ldk * 2;   // rows past the key range repeat its last row
-            dma16(kb, ko, st + (wid + 4 * i) * 1024);
-        }
-    };
-    auto issue_v = [&](int kt) {
-        const int kbase = ks + kt * 64;
-        const int valid = ke - kbase;
-        const bf16_t* vb = uniform_ptr(Vp + (long)kbase * p.ldv);
-        const unsigned st = __builtin_amdgcn_readfirstlane(smem_lds + NK * K_LDS + (kt & 1) * V_LDS);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int vo = v_off[i];
-            if (valid < 64) vo -= (st_row[i] - min(st_row[i], valid - 1)) * (int)p.ldv * 2;
-            dma16(vb, vo, st + (wid + 4 * i) * 1024);
-        }
-    };
-
-    const int krow0 = 8 * (li >> 2) + (li & 3);
-    const int vr = 8 * g + (li >> 2);
-    const int v_sw = v_swz(vr);
-    const int v_base = vr * 256 + ((li & 3) & 1) * 8;
-    const int v_ch = (li & 3) >> 1;
-    const bool wave_active = q0 + wid * 32 < qe;
-
-    // S(kt) - m_ref of all four 16-key blocks and both 16-row sub-tiles (32 MFMAs, 16 fragment reads)
-    auto qk_tile = [&](const int kt, f32x4 (&sx)[4][NQ]) {
-        const char* Ks = smem + (kt % NK) * K_LDS;
-#pragma unroll
-        for (int ut = 0; ut < 4; ++ut) {
-            const int krow = 32 * (ut >> 1) + 4 * (ut & 1) + krow0;
-            const int ksw = k_swz(krow);
-#pragma unroll
-            for (int s2 = 0; s2 < KS; ++s2) {
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + krow * 256 + (((4 * s2 + g) ^ ksw) << 4));
-#pragma unroll
-                for (int qi = 0; qi < NQ; ++qi) {
-                    const float nm = -m_ref[qi];
-                    const f32x4 c0 = f32x4{nm, nm, nm, nm};
-                    sx[ut][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf), qf[qi][s2],
-                                                                         s2 == 0 ? c0 : sx[ut][qi], 0, 0, 0);
-                }
-            }
-        }
-    };
-    auto mask_tile = [&](const int kt, f32x4 (&sx)[4][NQ]) {               // keys outside the range / right of the diagonal -> -inf
-        const int kbase = ks + kt * 64;
-#pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-            const int qloc = qrow[qi] - qs;
-#pragma unroll
-            for (int ut = 0; ut < 4; ++ut)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kbase + 32 * (ut >> 1) + 8 * g + 4 * (ut & 1) + r;
-                    if (!(key < ke && (key - ks) <= qloc + p.q_pos0)) sx[ut][qi][r] = -INFINITY;
-                }
-        }
-    };
-
-    // one iteration: consumes sc = S(kt) - m_ref (masked by the caller), produces sn = S(kt+1) - m_ref, adds tile kt to
-    // (O, l). ONE code variant on purpose: with masked / last-tile variants beside it (as the kernel above has) hipcc
-    // spills 120-350 registers; so the mask is a separate block before the step, and the step after the last tile
-    // computes scores of a tile that does not exist (its K slot holds an older tile or nothing; the result is never read):
-    // one tile of QK^T MFMAs per workgroup wasted, against a loop body that fits 242 registers.
-    auto step = [&](const int kt, f32x4 (&sc)[4][NQ], f32x4 (&sn)[4][NQ]) {
-        const char* Vs = smem + NK * K_LDS + (kt & 1) * V_LDS;
-        // ---- one basic block: the MFMAs of S(kt+1) beside the softmax arithmetic of tile kt
-        qk_tile(kt + 1, sn);
-        bf16x8 pf[2][NQ];
-        float dd[NQ];
-#pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-            float d = -INFINITY;
-#pragma unroll
-            for (int ut = 0; ut < 4; ++ut)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d = fmaxf(d, sc[ut][qi][r]);
-            d = colgroup_max(d);
-            dd[qi] = fmaxf(d, 0.f);                                     // how far this tile raises the row's maximum
-            float psum = 0.f;
-            float pv[4][4];
-#pragma unroll
-            for (int ut = 0; ut < 4; ++ut)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pv[ut][r] = __builtin_amdgcn_exp2f(sc[ut][qi][r]);
-                    psum += pv[ut][r];
-                }
-            l_run[qi] += psum;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                u32x4 w;
-                w[0] = pack_bf2(pv[2 * u][0], pv[2 * u][1]);
-                w[1] = pack_bf2(pv[2 * u][2], pv[2 * u][3]);
-                w[2] = pack_bf2(pv[2 * u + 1][0], pv[2 * u + 1][1]);
-                w[3] = pack_bf2(pv[2 * u + 1][2], pv[2 * u + 1][3]);
-                pf[u][qi] = __builtin_bit_cast(bf16x8, w);
-            }
-        }
-        // ---- O^T += V^T . P^T
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const char* va = Vs + u * 32 * 256 + v_base + ((((2 * d + v_ch) ^ v_sw)) << 4);
-                const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va));
-                const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(va + 4 * 256));
-                u32x4 w;
-                u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-                w[0] = l2[0]; w[1] = l2[1]; w[2] = h2[0]; w[3] = h2[1];
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, w);
-#pragma unroll
-                for (int qi = 0; qi < NQ; ++qi)
-                    oacc[d][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][qi], oacc[d][qi], 0, 0, 0);
-            }
-        }
-        // ---- rows whose maximum moved (wave-uniform test): rescale (O, l), shift the pending scores
-#pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-            if (__any(dd[qi] > 0.f)) {
-                const float al = __builtin_amdgcn_exp2f(-dd[qi]);
-                m_ref[qi] += dd[qi];
-                l_run[qi] *= al;
-#pragma unroll
-                for (int d = 0; d < DT; ++d) oacc[d][qi] *= al;
-#pragma unroll
-                for (int ut = 0; ut < 4; ++ut)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sn[ut][qi][r] -= dd[qi];
-            }
-        }
-    };
-
-    // leading tiles [0, t_mid) need no mask: fully inside the key range and left of the causal diagonal
-    int t_mid;
-    {
-        int full = (ke - ks) / 64;
-        const int lim = (q0 - qs) + p.q_pos0 - 63;
-        full = min(full, lim >= 0 ? lim / 64 + 1 : 0);
-        t_mid = max(0, min(full, nt));
-    }
-    // ---- prologue: K(0), V(0), K(1) on their way; S(0) with its reference maximum
-    issue_k(0);
-    issue_v(0);
-    if (nt > 1) issue_k(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi)
-#pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) asm volatile("" : "+v"(qf[qi][s2]));     // Q loads complete before the loop
-    __builtin_amdgcn_s_barrier();
-    f32x4 sa[4][NQ], sb[4][NQ];
-    if (wave_active) {
-        qk_tile(0, sa);                                                           // m_ref = 0
-        if (t_mid == 0) mask_tile(0, sa);
-#pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-            float d = -INFINITY;
-#pragma unroll
-            for (int ut = 0; ut < 4; ++ut)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d = fmaxf(d, sa[ut][qi][r]);
-            d = colgroup_max(d);
-            const float d0 = (d == -INFINITY) ? 0.f : d;
-            m_ref[qi] = d0;
-#pragma unroll
-            for (int ut = 0; ut < 4; ++ut)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sa[ut][qi][r] -= d0;
-        }
-    }
-    auto tile = [&](const int kt, f32x4 (&sc)[4][NQ], f32x4 (&sn)[4][NQ]) {
-        // K(kt+1) and V(kt) are visible to all; the slots of K(kt-1) and V(kt-1) are no longer read by anyone
-        if (kt + 2 < nt) issue_k(kt + 2);
-        if (kt + 1 < nt) issue_v(kt + 1);
-        if (wave_active) {
-            if (kt >= t_mid) mask_tile(kt, sc);
-            step(kt, sc, sn);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of K(kt+2) and V(kt+1) have landed
-        __builtin_amdgcn_s_barrier();
-    };
-    for (int kt = 0; kt < nt; kt += 2) {
-        tile(kt, sa, sb);
-        if (kt + 1 < nt) tile(kt + 1, sb, sa);
     }
 
     bf16_t* Op = reinterpret_cast<bf16_t*>(p.O);
@@ -2109,12 +1825,7 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
             // 1 024 cycles of MFMA, because every K / V fragment read from LDS feeds only two MFMAs (32 query rows per
             // wave): 48 LDS reads per 64 MFMAs. Off by default; debug switch attn_prefill_pp = 1 selects it.
             const bool env_pp = g_cogs_debug.attn_prefill_pp == 1;
-            if (g_cogs_debug.attn_prefill_sp && !g_cogs_debug.attn_prefill64 && !env_pp) {
-                static std::atomic<uint64_t> attr_done_sp{0};
-                cogs_ensure_dyn_lds((const void*)attn_prefill_sp_kernel, 80 * 1024, attr_done_sp);
-                g_cogs_debug.attn_last_kernel = 10;
-                hipLaunchKernelGGL(attn_prefill_sp_kernel, grid, dim3(256), 80 * 1024, st, p);
-            } else if (g_cogs_debug.attn_prefill64 && max_len >= 256) {
+            if (g_cogs_debug.attn_prefill64 && max_len >= 256) {
                 static std::atomic<uint64_t> attr_done64{0};
                 cogs_ensure_dyn_lds((const void*)attn_prefill64_kernel, 4 * 32 * 1024, attr_done64);
                 g_cogs_debug.attn_last_kernel = 9;

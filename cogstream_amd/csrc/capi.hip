@@ -182,7 +182,7 @@ const char* cogs_debug_list(void) {
         "gemm_last_body (read only): body the last cogs_gemm dispatched to -- 1 128x128, 2 256x128 ring, 3 K-tile ping-pong, "
         "4 whole-line ping-pong, 5 ping-pong + ring (split launch), 6 GEMV\n"
         "attn_last_kernel (read only): kernel of the last cogs_attention -- 1 general MFMA, 2 ViT unpipelined, 3 ViT pipelined, "
-        "4 single-token decode, 5 prompt LDS-DMA, 6 prompt ping-pong, 7 row-wise fp32, 8 ViT pipelined on head-major K/V, 9 prompt kernel with 64 query rows per wave, 10 software-pipelined prompt kernel\n";
+        "4 single-token decode, 5 prompt LDS-DMA, 6 prompt ping-pong, 7 row-wise fp32, 8 ViT pipelined on head-major K/V, 9 prompt kernel with 64 query rows per wave\n";
 }
 
 cogs_status cogs_create(int device, cogs_handle* out) {

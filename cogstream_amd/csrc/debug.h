@@ -32,7 +32,6 @@
     X(attn_combine32, 1, "split-KV combine: 1 one block per (head, 32-column slice), 8 loads in flight per thread; 0 one block per head") \
     X(attn_prefill_dma, 1, "0: Qwen2 prompt attention through the general register-staged kernel")                          \
     X(attn_prefill_deep, 1, "prompt LDS-DMA kernel: 1 fragment reads ordered 6-8 ahead of their MFMAs + running maximum deferred to 2^6 (round 5: 1.82 -> 1.64 ms), 0 the round-4 kernel") \
-    X(attn_prefill_sp, 0, "1: Qwen2 prompt attention software-pipelined across key tiles (S(t+1) beside softmax(t); round 5: correct, measured 2.15 vs 1.64 ms -- off)") \
     X(attn_prefill64, 0, "1: Qwen2 prompt attention with 64 query rows per wave, software-pipelined (round 5: correct, measured 2.94 vs 1.97 ms per layer -- off)") \
     X(attn_prefill_pp, 0, "1: ping-pong form of the prompt attention (bit-identical, measured slower)")                     \
     X(attn_prio, 2, "prompt attention wave priorities: 0 none, 1 MFMA phases raised, 2 softmax phase raised")               \
@@ -52,7 +51,7 @@ struct CogsDebug {
     // 0 none yet, 1 128x128, 2 256x128 ring, 3 K-tile ping-pong, 4 whole-line ping-pong, 5 ping-pong + ring (split), 6 GEMV
     long long gemm_last_body = 0;
     // ... and the last cogs_attention: 1 general MFMA kernel, 2 ViT unpipelined, 3 ViT pipelined (row-major K/V), 4 single-token
-    // decode (+ combine), 5 prompt LDS-DMA kernel, 6 prompt ping-pong kernel, 7 row-wise fp32 kernel, 8 ViT pipelined, head-major K/V, 9 prompt kernel with 64 rows per wave, 10 software-pipelined prompt kernel
+    // decode (+ combine), 5 prompt LDS-DMA kernel, 6 prompt ping-pong kernel, 7 row-wise fp32 kernel, 8 ViT pipelined, head-major K/V, 9 prompt kernel with 64 rows per wave
     long long attn_last_kernel = 0;
 };
 extern CogsDebug g_cogs_debug;     // capi.hip
