@@ -25,6 +25,8 @@
     X(gemm_trace, 0, "1: per-tile s_memtime stamps of workgroup 0 printed to stderr (synchronises)")                        \
     X(gemm_choice, 0, "1: print which body every ping-pong-eligible shape gets")                                            \
     X(gemm_headmajor, 1, "ViT encode: QKV GEMM writes q/k/v head-major [which][head][row][hd] for the attention kernel")    \
+    X(gemv_small_n, 1024, "GEMV: 2 output rows per wave while N / 16 is below this (else 4)") \
+    X(gemv_dot2, 1, "bf16 GEMV (decode): 1 products on v_dot2c_f32_bf16 from the packed registers (round 5), 0 unpack + fp32 fma per element") \
     /* ---- attention (csrc/attn.hip, attn_vit.hip, attn_decode.hip) ---- */                                                \
     X(attn_vit, 2, "ViT block-diagonal attention: 2 pipelined LDS-DMA kernel, 1 unpipelined, 0 general kernel")            \
     X(attn_vit_early, 0, "1: pipelined ViT kernel issues tiles 1-2 before its first wait (the order before round 4)")       \

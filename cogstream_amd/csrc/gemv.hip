@@ -9,6 +9,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "gemm_epilogue.h"
+#include "debug.h"
 
 // 16-byte chunks per row in flight per lane (R * U = 8 loads); swept with tools/micro/gemv_micro.cpp: (2 rows, U 4) and
 // (4 rows, U 2) are the fastest or level on every decode shape (U 7 / 8 / 3 / 4: within +-4 %, each slower somewhere)
@@ -58,6 +59,12 @@ __device__ __forceinline__ void rms_apply_reg(float (&x)[8], const float (&g)[8]
     }
 }
 
+// acc + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a), __builtin_bit_cast(bf2_t, b), acc, false);
+}
+
 // epilogue of 2 consecutive output columns n, n+1 (one rotary / SwiGLU pair): same arithmetic as epilogue4
 template <typename T>
 __device__ __forceinline__ void epilogue2(const EpiArgs& p, int n, float v0, float v1) {
@@ -94,7 +101,13 @@ __device__ __forceinline__ void epilogue2(const EpiArgs& p, int n, float v0, flo
 // R output rows per wave (4: big N; 2: N so small that 4 rows per wave would leave CUs without enough bytes in
 // flight -- the 3584-row o/down projections launched 224 workgroups on 256 CUs and ran at 2-5 TB/s), U chunks of
 // 16 bytes per row in flight per lane (R*U = 8 independent loads, kept raw until used).
-template <typename T, int R, int U>
+// DOT2 (round 5, bf16 only): the products run on v_dot2c_f32_bf16 -- two bf16 x bf16 products and an fp32 accumulate per instruction,
+// straight from the packed registers -- instead of unpacking both operands (1 VALU each) for an fp32 fma per element: 8 VALU per
+// 16-byte weight chunk instead of 16 + 8 (+ 8 for x). The small GEMVs are bound by exactly that: a wave of the qkv projection
+// spent ~840 vector instructions on 14 KB of weights (56 normalised x values, unpacked and rounded per wave, times 2 rows).
+// The normalised x is formed once per wave as packed bf16 pairs -- the same values as before, bit for bit; the sums differ from
+// the fma chain's in the last fp32 bits only (products exact either way, two-term partial sums before the accumulate).
+template <typename T, int R, int U, bool DOT2 = false>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
     const int lane = threadIdx.x & 63;
@@ -163,6 +176,38 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
             float accr[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) accr[r] = 0.f;
+            if constexpr (DOT2) {
+                // weight * (x * rstd).to(bf16), rounded to bf16: rms_apply_reg's values, kept as packed pairs
+                // (sharing this between the four waves of a workgroup through LDS -- a quarter of the work per wave, one barrier --
+                // was measured slower: 2.887 vs 2.877 ms per token)
+#pragma unroll
+                for (int i = 0; i < XC; ++i) {
+                    u32x4 xn;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t t = pack_bf2(bf_lo(xall[i][e]) * rstd, bf_hi(xall[i][e]) * rstd);
+                        xn[e] = pack_bf2(bf_lo(gall[i][e]) * bf_lo(t), bf_hi(gall[i][e]) * bf_hi(t));
+                    }
+                    xall[i] = xn;
+                }
+#pragma unroll
+                for (int b0 = 0; b0 < XC; b0 += U) {
+                    u32x4 wr[U][R];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (b0 + u < XC) wr[u][r] = b0 == 0 ? w_first[u][r] : ldw(w[r] + (lane + 64 * (b0 + u)) * EPC);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (b0 + u >= XC) continue;
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) accr[r] = dot2_bf16(wr[u][r][e], xall[b0 + u][e], accr[r]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int b0 = 0; b0 < XC; b0 += U) {
                 constexpr int dummy = 0; (void)dummy;
@@ -187,6 +232,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
                         for (int e = 0; e < EPC; ++e) accr[r] += wa[e] * xa[e];
                     }
                 }
+            }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) accr[r] = wave_sum(accr[r]);
@@ -223,6 +269,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
         for (int u = 0; u < U; ++u) xr[u] = *reinterpret_cast<const u32x4*>(x + (ch + 64 * u) * EPC);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if constexpr (DOT2) {
+                if (!gam) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[r] = dot2_bf16(w_first[u][r][e], xr[u][e], acc[r]);
+                    continue;
+                }
+            }
             float xa[EPC];
             to_f(xr[u], xa);
             if (gam) rms_apply<T, EPC>(xa, gam + (ch + 64 * u) * EPC, rstd);
@@ -247,6 +302,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
         for (int u = 0; u < U; ++u) xr[u] = *reinterpret_cast<const u32x4*>(x + (ch + 64 * u) * EPC);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if constexpr (DOT2) {
+                if (!gam) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[r] = dot2_bf16(wr[u][r][e], xr[u][e], acc[r]);
+                    continue;
+                }
+            }
             float xa[EPC];
             to_f(xr[u], xa);
             if (gam) rms_apply<T, EPC>(xa, gam + (ch + 64 * u) * EPC, rstd);
@@ -263,8 +327,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
         u32x4 wr[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) wr[r] = ldw(w[r] + ch * EPC);
+        if constexpr (DOT2) {
+            if (!gam) {
+                const u32x4 xraw = *reinterpret_cast<const u32x4*>(x + ch * EPC);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[r] = dot2_bf16(wr[r][e], xraw[e], acc[r]);
+                continue;
+            }
+        }
         float xa[EPC];
-        to_f(*reinterpret_cast<const u32x4*>(x + ch * EPC), xa);
+        to_f(*reinterpret_cast<const u32x4*>(x + ch * EPC), xa);    // (this spelling: hoisting the load above the block doubles hipcc's register count)
         if (gam) rms_apply<T, EPC>(xa, gam + ch * EPC, rstd);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -301,14 +375,17 @@ int cogs_k_gemv(hipStream_t st, const CogsGemm& g) {
     p.kv_k = (char*)g.kv_k; p.kv_v = (char*)g.kv_v; p.kv_col0 = g.kv_col0; p.kv_dim = g.kv_dim;
     if (g.kv_k && (g.kv_col0 % 4 || g.kv_dim % 4 || g.out_f32 || g.act == COGS_ACT_SWIGLU)) return COGS_E_INVALID;
     // 4 rows per wave when that still gives every CU several workgroups, else 2 (N % 4 == 0 keeps pairs whole)
-    const bool small_n = g.N / 16 < 1024;
+    const bool small_n = g.N / 16 < (int)g_cogs_debug.gemv_small_n;
+    const bool dot2 = g_cogs_debug.gemv_dot2 != 0;
     if (small_n) {
         const int grid = (g.N / 2 + 3) / 4;
-        if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL((gemv_kernel<bf16_t, 2, GEMV_U_SMALL>), dim3(grid), dim3(256), 0, st, p);
+        if (g.dtype == COGS_DT_BF16 && dot2) hipLaunchKernelGGL((gemv_kernel<bf16_t, 2, GEMV_U_SMALL, true>), dim3(grid), dim3(256), 0, st, p);
+        else if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL((gemv_kernel<bf16_t, 2, GEMV_U_SMALL>), dim3(grid), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemv_kernel<float, 2, 4>), dim3(grid), dim3(256), 0, st, p);
     } else {
         const int grid = (g.N / 4 + 3) / 4;
-        if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL((gemv_kernel<bf16_t, 4, GEMV_U_BIG>), dim3(grid), dim3(256), 0, st, p);
+        if (g.dtype == COGS_DT_BF16 && dot2) hipLaunchKernelGGL((gemv_kernel<bf16_t, 4, GEMV_U_BIG, true>), dim3(grid), dim3(256), 0, st, p);
+        else if (g.dtype == COGS_DT_BF16) hipLaunchKernelGGL((gemv_kernel<bf16_t, 4, GEMV_U_BIG>), dim3(grid), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemv_kernel<float, 4, 2>), dim3(grid), dim3(256), 0, st, p);
     }
     return COGS_LAUNCH_CHECK();

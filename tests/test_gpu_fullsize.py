@@ -252,3 +252,40 @@ def test_prompt_attention_in_the_19_sequence_event_form_vs_fp32(dev, kernel):
     err = (got - ref).abs().view(len(rows), hq, hd).amax(2) / ref.abs().view(len(rows), hq, hd).amax(2).clamp_min(1e-3)
     assert float(err.max()) < 2e-2, (float(err.max()), int(rows[int(err.argmax()) // hq]))
     assert rel_err(got, ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("dot2", [1, 0])
+def test_decode_gemvs_at_production_width_vs_oracle(dev, dot2):
+    """The decode GEMVs at Qwen2-7B's widths (hidden 3 584, 28 / 4 heads, intermediate 18 944: the register-resident fused-RMSNorm
+    path only exists for K = 3 584) -- one layer, a small vocabulary, a 130-token prompt and three generated tokens -- against
+    the fp32 oracle, with the products on v_dot2c_f32_bf16 (the default, round 5) and with the unpack + fma form it replaced;
+    the two must also agree with each other to a bf16 rounding."""
+    from cogstream_amd import _lib as L
+    from cogstream_amd.llm import Qwen2Engine
+    from cogstream_amd.weights import LlmConfig, random_llm_state
+    from oracle import qwen2 as oq
+    _cpu_threads()
+    cfg = LlmConfig(num_hidden_layers=1, vocab_size=1024, image_token_index=1000, eos_token_id=999)
+    st = random_llm_state(cfg, seed=11, std=0.02)
+    eng = Qwen2Engine(st, cfg, dtype=torch.bfloat16, device=dev)
+    kw = dict(heads=cfg.num_attention_heads, kv_heads=cfg.num_key_value_heads, layers=cfg.num_hidden_layers)
+    torch.manual_seed(12)
+    emb = torch.randn(130, cfg.hidden_size) * 0.5
+    hid, kv = oq.forward(st, emb, **kw)
+    outs = {}
+    for sw in (dot2, 1 - dot2):
+        with L.debug_switch("gemv_dot2", sw):
+            cache = eng.new_cache(160)
+            eng.forward(emb.to(dev, torch.bfloat16), cache)
+            torch.manual_seed(13)
+            kv_s, got = kv, []
+            for step in range(3):
+                e = torch.randn(1, cfg.hidden_size) * 0.5
+                r = eng.forward(e.to(dev, torch.bfloat16), cache)
+                assert L.debug_get("gemm_last_body") == 6                     # the lm_head went through the GEMV
+                if sw == dot2:
+                    h1, kv_s = oq.forward(st, e, past=kv_s, **kw)
+                    assert rel_err(r["logits"], oq.logits(st, h1[-1])) < 3e-2
+                got.append(r["logits"].float().cpu())
+            outs[sw] = torch.stack(got)
+    assert rel_err(outs[1], outs[0]) < 1e-2
