@@ -16,7 +16,7 @@ typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 
 // MODE: 0 MFMA16 only (8 per iter), 1 exp only (8 per iter), 2 8 MFMA16 + 8 exp interleaved, 3 8 MFMA16 + 4 exp,
 //       4 add only (32 per iter), 5 8 MFMA16 + 32 add, 6 MFMA32 only (4 per iter), 7 4 MFMA32 + 8 exp, 8 4 MFMA32 + 32 add,
-//       9 8 MFMA16 + 4 exp + 16 add, 10 odd waves MFMA16 only / even waves exp only (two waves per SIMD)
+//       9 8 MFMA16 + 4 exp + 16 add, 10 odd waves MFMA16 only / even waves exp only (two waves per SIMD), 11-14 dependent accumulator chains
 template <int MODE>
 __global__ void k(long long* out, int iters) {
     bf16x8 a, b;
@@ -40,6 +40,10 @@ __global__ void k(long long* out, int iters) {
         if constexpr (MODE == 7) { for (int i = 0; i < 4; ++i) { MF32(C[i]); EXP(x[2 * i]); EXP(x[2 * i + 1]); } }
         if constexpr (MODE == 8) { for (int i = 0; i < 4; ++i) { MF32(C[i]); for (int j = 0; j < 8; ++j) ADD(x[j]); } }
         if constexpr (MODE == 9) { for (int i = 0; i < 8; ++i) { MF16(c[i]); if (i & 1) EXP(x[i]); ADD(x[(i + 2) & 7]); ADD(x[(i + 4) & 7]); } }
+        if constexpr (MODE == 11) { for (int i = 0; i < 4; ++i) MF32(C[0]); }                       // ONE accumulator: a dependent chain
+        if constexpr (MODE == 12) { for (int i = 0; i < 8; ++i) MF16(c[0]); }
+        if constexpr (MODE == 13) { for (int i = 0; i < 4; ++i) { MF32(C[0]); EXP(x[2 * i]); EXP(x[2 * i + 1]); } }     // chain + exps in its gaps
+        if constexpr (MODE == 14) { for (int i = 0; i < 2; ++i) { MF32(C[0]); MF32(C[1]); } }          // two interleaved chains
         if constexpr (MODE == 10) {
             if (w & 4) { for (int i = 0; i < 8; ++i) MF16(c[i]); } else { for (int i = 0; i < 8; ++i) EXP(x[i]); }
         }
@@ -85,6 +89,10 @@ int main() {
         run<6>("4 MFMA 32x32x16", th, d);
         run<7>("4 MFMA 32x32x16 + 8 v_exp_f32", th, d);
         run<8>("4 MFMA 32x32x16 + 32 v_add_f32", th, d);
+        run<11>("4 MFMA 32x32x16 on ONE accumulator (dependent chain)", th, d);
+        run<14>("4 MFMA 32x32x16 on two accumulators, alternating", th, d);
+        run<13>("4 MFMA 32x32x16 on one accumulator + 8 v_exp_f32 between them", th, d);
+        run<12>("8 MFMA 16x16x32 on ONE accumulator (dependent chain)", th, d);
     }
     run<10>("waves 4-7: 8 MFMA 16x16x32; waves 0-3: 8 v_exp_f32 (per SIMD one of each)", 512, d);
     return 0;
