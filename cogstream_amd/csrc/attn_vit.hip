@@ -48,8 +48,9 @@ struct VitAttnArgs {
 
 constexpr float RESCALE_THR = 6.0f;
 
-#if defined(COGS_ATTN_STAMPS) || defined(COGS_PIPE_STAMPS)   // diagnostic builds (tools/micro/attn_vit_micro.cpp)
+#if defined(COGS_ATTN_STAMPS) || defined(COGS_PIPE_STAMPS) || defined(COGS_PHASE_STAMPS)   // diagnostic builds (tools/micro/attn_vit_micro.cpp)
 __device__ unsigned long long g_attn_stamps[8];
+__device__ unsigned long long g_tail_stamps[8];
 #endif
 #ifdef COGS_ATTN_STAMPS   // where does a tile's time go, wave 0 of one workgroup
 #define STAMP(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - st_prev; st_prev = now_; } while (0)
@@ -420,6 +421,11 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #else
 #define PSTAMP() do {} while (0)
 #endif
+#ifdef COGS_PHASE_STAMPS      // tools/experiments/attn_vit_phases.sh: where a main-loop tile's time goes, wave 0 of one workgroup
+#define PHT(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PHT(v) do {} while (0)
+#endif
     PSTAMP();      // 0: kernel entry
     int seg, head, qb;
     {
@@ -715,13 +721,24 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             }
         }
     };
+#ifdef COGS_PHASE_STAMPS
+    unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     auto tile_head = [&](const int t, auto slot_tag) {       // slot_tag: ring slot of tile t when known at compile time, else -1
         constexpr int SLOT = decltype(slot_tag)::value;
         // outstanding, oldest first: tile t+1 (if any), tile t+2 (if any); tile t+1 must have landed
+        unsigned long long h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+        PHT(h0);
         wait_tiles(t + 2 < nt ? 1 : 0);
+        PHT(h1);
         __builtin_amdgcn_s_barrier();     // K(t+1), V(t) visible to all; slot of tile t-1 no longer read by anyone
+        PHT(h2);
 #ifndef ABL_NOLOAD
         if (t + 3 < nt) issue_tile(t + 3, SLOT >= 0 ? (SLOT + 3) & (NS - 1) : (t + 3) & (NS - 1));
+#endif
+        PHT(h3);
+#ifdef COGS_PHASE_STAMPS
+        ph_acc[0] += h1 - h0; ph_acc[1] += h2 - h1; ph_acc[2] += h3 - h2; ph_acc[3] += 1;
 #endif
     };
 
@@ -736,11 +753,21 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #else
 #define COGS_AV_ACTIVE wave_active
 #endif
+#ifdef COGS_PHASE_STAMPS
+#define COGS_PH_ADD(a_, b_, c_) ph_acc[4] += (b_) - (a_); ph_acc[5] += (c_) - (b_);
+#else
+#define COGS_PH_ADD(a_, b_, c_)
+#endif
 #define COGS_AV_TILE(I)                                                                                      \
         tile_head(t + I, std::integral_constant<int, I>{});                                                  \
         if (COGS_AV_ACTIVE) {                                                                                \
+            unsigned long long c0_ = 0, c1_ = 0, c2_ = 0;                                                    \
+            PHT(c0_);                                                                                        \
             substep(sa, sb, 2 * (t + I), Full{}, std::integral_constant<int, I>{});                          \
+            PHT(c1_);                                                                                        \
             substep(sb, sa, 2 * (t + I) + 1, Full{}, std::integral_constant<int, I>{});                      \
+            PHT(c2_);                                                                                        \
+            COGS_PH_ADD(c0_, c1_, c2_)                                                                       \
         }
         COGS_AV_TILE(0) COGS_AV_TILE(1) COGS_AV_TILE(2) COGS_AV_TILE(3)
 #undef COGS_AV_TILE
@@ -755,9 +782,22 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         }
 #endif
     }
+#ifdef COGS_PHASE_STAMPS
+    if (blockIdx.x == 3000 && tid == 0) { for (int i = 0; i < 8; ++i) g_attn_stamps[i] = ph_acc[i]; }
+#endif
     PSTAMP();      // 3: main loop done
+#ifdef COGS_PHASE_STAMPS
+    unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int tl_n = 0;
+#endif
     for (; t < nt; ++t) {                         // the ragged end: block kinds decided at run time (wave-uniform)
+        unsigned long long q0_ = 0, q1_ = 0;
+        PHT(q0_);
         tile_head(t, std::integral_constant<int, -1>{});
+        PHT(q1_);
+#ifdef COGS_PHASE_STAMPS
+        tl_acc[0] += q1_ - q0_;
+#endif
         if (!wave_active) continue;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -765,11 +805,21 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             if (j >= nblk) break;
             f32x16& sc = kb == 0 ? sa : sb;
             f32x16& sn = kb == 0 ? sb : sa;
+            unsigned long long u0_ = 0, u1_ = 0;
+            PHT(u0_);
             if (j + 1 < nfull) substep(sc, sn, j, Full{}, std::integral_constant<int, -1>{});
             else if (j + 1 < nblk) substep(sc, sn, j, std::integral_constant<int, 3>{}, std::integral_constant<int, -1>{});
             else substep(sc, sn, j, std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{});
+            PHT(u1_);
+#ifdef COGS_PHASE_STAMPS
+            if (tl_n < 6) tl_acc[1 + tl_n] = u1_ - u0_;
+            ++tl_n;
+#endif
         }
     }
+#ifdef COGS_PHASE_STAMPS
+    if (blockIdx.x == 3000 && tid == 0) { for (int i = 0; i < 8; ++i) g_tail_stamps[i] = tl_acc[i]; }
+#endif
     PSTAMP();      // 4: tail done
     if (!wave_active) return;
 

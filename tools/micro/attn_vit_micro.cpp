@@ -57,6 +57,19 @@ int main(int argc, char** argv) {
     printf("per full tile, wave 0 of one workgroup (cycles): barrier wait %.0f | stage %.0f | QK (to results) %.0f | softmax %.0f | PV issue %.0f | sum %.0f\n",
            st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, (st[0] + st[1] + st[2] + st[3] + st[4]) / n);
 #endif
+#ifdef COGS_PHASE_STAMPS
+    {
+        unsigned long long st[8];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_attn_stamps), sizeof(st));
+        const double n = (double)st[3] + 1e-9;
+        printf("workgroup 3000, wave 0, %d main-loop tiles, shader cycles per tile: wait for tile t+1 %.0f | barrier %.0f | issue of tile t+3 %.0f | sub-step 0 %.0f | sub-step 1 %.0f | sum %.0f\n",
+               (int)n, st[0] / n, st[1] / n, st[2] / n, st[4] / n, st[5] / n, (st[0] + st[1] + st[2] + st[4] + st[5]) / n);
+        unsigned long long tl[8];
+        hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_tail_stamps), sizeof(tl));
+        printf("   the ragged end of the same wave (cycles): tile heads (wait + barrier + issue) %llu in all | sub-steps in order: %llu %llu %llu %llu %llu\n",
+               tl[0], tl[1], tl[2], tl[3], tl[4], tl[5]);
+    }
+#endif
 #ifdef COGS_PIPE_STAMPS
     {
         unsigned long long st[8];
