@@ -528,6 +528,12 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         else { if (n_own == 2 * NPI + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NPI + 2) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NPI) : "memory"); }
     };
 
+#ifndef AV_LATE_ISSUE
+    // Round 5: tile 0 goes out HERE, as soon as its addresses exist -- in front of the ~800 cycles of per-lane read offsets,
+    // accumulator zeroing and fragment-address setup below, which then run under the memory round trip instead of in front of it
+    // (inline-asm DMA is a scheduling boundary for hipcc: where the statement stands is where the instruction goes).
+    issue_tile(0, 0);
+#endif
     // per-lane LDS read offsets inside a stage. K: lane (key r32, k-half h) reads 16 bytes at column 32 ks + 16 h; in
     // the last k-step half 1 is the pad chunk -> constant [1, 0 x7]
     const int k_rd = r32 * RS + h * 16;
@@ -621,7 +627,9 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #ifdef COGS_PIPE_STAMPS2
     PSTAMP();      // Q loads issued
 #endif
+#ifdef AV_LATE_ISSUE
     issue_tile(0, 0);
+#endif
     // round 4: only Q and tile 0 go out before the first wait (10 vector-memory instructions per wave instead of 18: the
     // CU's vector-memory path takes one 1 KiB piece per ~60-115 cycles, so the 8 pieces of tiles 1 and 2 used to stand
     // between every wave and its first MFMA); tiles 1 and 2 follow behind the barrier, in order, so the counted waits of
