@@ -11,6 +11,7 @@
 #define COGS_DEBUG_SWITCHES(X)                                                                                              \
     /* ---- GEMM (csrc/gemm.hip) ---- */                                                                                    \
     X(gemm_pp64, 1, "1: whole-line ping-pong kernel (gemm_tn_pp64_kernel); 0: the 32-wide K-tile body it replaced")         \
+    X(gemm_tall, 1, "whole-line kernel: 1 a ragged column block of <= 128 columns as 384x128 tiles (round 6), 0 as padded 256x256 tiles") \
     X(gemm_pingpong, 1, "0: never take a ping-pong kernel (256x128 ring / 128x128 kernels only)")                          \
     X(gemm_small, 0, "1: always the 128x128 kernel")                                                                        \
     X(gemm_wgs, 256, "persistent workgroups of the 256x128 ring kernel (0: one tile per workgroup)")                        \

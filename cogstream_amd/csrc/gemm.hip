@@ -47,6 +47,8 @@ struct GemmArgs {
     int nbm, nbn;
     const float* rope_lut; int rope_lut_bytes;   // EPI_ROPE_LUT: global LUT copied to LDS behind the ring at kernel start
     int group_m;                 // ping-pong kernel: row blocks per group of the tile walk (L2 footprint of an XCD)
+    int cf;                      // whole-line ping-pong kernel: tiles of a FULL group = group_m * nbn (+ its tall tiles: see TALL4)
+    int ntiles;                  //   ... and the tiles of the whole launch
     int epi_serial;              // whole-line kernel, A/B runs (debug switch gemm_epi_serial): both groups' epilogues behind the tile's last barrier
     unsigned long long* trace;   // diagnostics (debug switch gemm_trace): per-tile s_memtime stamps of WG 0, waves 0 and 4
     EpiArgs epi;
@@ -617,9 +619,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
 // intervals carries 16 pieces, as in the kernel above, but of whole lines. One counted vmcnt per slab: behind the units a
 // slab needs, each wave has issued 12 newer pieces (A(s+2), W(s+2), A(s+3)), plus, across a tile boundary, the epilogue's
 // loads and stores (exact-count rule as above, else a stricter count that waits for them too).
+//
+// TALL tiles (round 6). N = 1152 is 4.5 column blocks of 256 and N = 3456 is 13.5: as a whole 256x256 tile the ragged block
+// spends half its MFMAs on columns that do not exist (9.9 % / 3.7 % of those launches' matrix-pipe cycles). It is walked as
+// tiles of 384 rows x 128 columns instead, through the SAME ring with the SAME piece and wait counts: the "A unit" of a slab
+// is rows 0..255 of the tile as always; the "W unit" carries rows 256..383 of the tile in its rows 0..127 (staged by waves
+// 0..3) and the 128 weight rows in its rows 128..255 (waves 4..7). The 384 x 128 outputs are six 128 x 64 wave regions:
+// wave (group g, column wc) takes rows 128 wc.., columns 64 g.. for wc < 3 (wc == 2 reads its A fragments from the W unit),
+// and the two waves with wc == 3 -- one SIMD -- only stage and keep the barriers. Every output element still sees the same
+// MFMAs over the same K order, so a row's bits do not depend on which kind of tile produced it; three ragged half tiles
+// cost two tile times instead of three.
 constexpr int ROW4 = 128;                         // bytes per LDS row = 64 bf16 = one line of the operand
 constexpr int UNIT4 = 256 * ROW4;                 // 32 KiB: the A rows or the W rows of one slab
 constexpr int RING4 = 5;
+constexpr int TALL4 = 384;                        // rows of a tall tile (its columns: the <= 128 of the ragged column block)
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
@@ -631,18 +644,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wid >> 2;          // 0: rows 0..127 of the tile, 1: rows 128..255; also the stagger group
     const int wc = wid & 3;
-    const int nb = p.nbm * p.nbn;
+    const int nb = p.ntiles;
     const int KS = p.K / 64;
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    auto tile_origin = [&](int t, int& m0, int& n0) {
+    // Tile walk: groups of group_m row blocks; a group's whole 256x256 tiles column by column, then -- when N leaves a ragged
+    // column block of <= 128 columns (p.cf > group_m * nbn; p.nbn then counts the WHOLE column blocks only) -- its TALL tiles:
+    // 384 rows x 128 columns of that ragged block (kind 1, see TALL4 below). Only the last group can be short, so a tile's
+    // group is bid / cf.
+    auto tile_origin = [&](int t, int& m0, int& n0, int& kind) {
         const int xcd = t & 7, q = nb >> 3, r = nb & 7;
         const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
-        const int per_group = p.group_m * p.nbn;
-        const int first_m = (bid / per_group) * p.group_m;
+        const int gi = bid / p.cf, idx = bid - gi * p.cf;
+        const int first_m = gi * p.group_m;
         const int gsz = min(p.nbm - first_m, p.group_m);
-        m0 = (first_m + (bid % per_group) % gsz) * BM3;
-        n0 = ((bid % per_group) / gsz) * BN3;
+        const int nnorm = gsz * p.nbn;
+        if (idx < nnorm) {
+            m0 = (first_m + idx % gsz) * BM3;
+            n0 = (idx / gsz) * BN3;
+            kind = 0;
+        } else {
+            m0 = first_m * BM3 + (idx - nnorm) * TALL4;
+            n0 = p.nbn * BN3;
+            kind = 1;
+        }
     };
 
     // staging: a unit is 32 pieces of 1 KiB (8 rows x 128 B); wave w owns pieces 4w..4w+3 of EVERY unit (rows 32w..32w+31).
@@ -653,8 +678,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
     int voff_a[4], voff_w[4];
     int sa_t = blockIdx.x, sa_ks = 0, sw_t = blockIdx.x, sw_ks = 0;
     auto set_src_a = [&](int t) {
-        int m0, n0;
-        tile_origin(t, m0, n0);
+        int m0, n0, kind;
+        tile_origin(t, m0, n0, kind);
         base_a = (unsigned long long)p.A + (unsigned long long)m0 * p.lda;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -663,13 +688,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
         }
     };
     auto set_src_w = [&](int t) {
-        int m0, n0;
-        tile_origin(t, m0, n0);
-        base_w = (unsigned long long)p.W + (unsigned long long)n0 * p.ldw;
+        int m0, n0, kind;
+        tile_origin(t, m0, n0, kind);
+        if (kind != 0 && wid < 4) {
+            // tall tile, waves 0..3: rows 256..383 of the tile -> rows 0..127 of the W unit (the offset is unsigned: base = tile origin)
+            base_w = (unsigned long long)p.A + (unsigned long long)m0 * p.lda;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = n0 + wid * 32 + i * 8 + (lane >> 3);
-            voff_w[i] = (min(r, p.N - 1) - n0) * (int)p.ldw + (((lane & 7) ^ (lane >> 3)) << 4);
+            for (int i = 0; i < 4; ++i) {
+                const int r = m0 + 256 + wid * 32 + i * 8 + (lane >> 3);
+                voff_w[i] = (min(r, p.M - 1) - m0) * (int)p.lda + (((lane & 7) ^ (lane >> 3)) << 4);
+            }
+        } else {
+            // weight rows: 256 of them over all eight waves, or (tall tile) 128 over waves 4..7 -> rows 128..255 of the unit
+            const int w0 = kind != 0 ? (wid - 4) * 32 : wid * 32;
+            base_w = (unsigned long long)p.W + (unsigned long long)n0 * p.ldw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = n0 + w0 + i * 8 + (lane >> 3);
+                voff_w[i] = (min(r, p.N - 1) - n0) * (int)p.ldw + (((lane & 7) ^ (lane >> 3)) << 4);
+            }
         }
     };
     const unsigned lds_wave = smem_lds + wid * 4096;
@@ -705,8 +742,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
 
     // fragment read offsets inside a unit: row r = lane&15, k-chunk (lane>>4) of the slab's first half; the second half is ^ 64
     const int foff = (lane & 15) * ROW4 + (((lane >> 4) ^ (lane & 7)) << 4);
-    const int a_off = (grp * 128) * ROW4 + foff;                 // + 64*ROW4 + mi*16*ROW4
-    const int w_off = (wc * 64) * ROW4 + foff;                   // + ni*16*ROW4
+    int a_off, w_off;      // per tile: the wave's first A row / W row inside their units (+ 64*ROW4 + mi*16*ROW4, + ni*16*ROW4)
+    int a_in_w = 0;        // tall tile, wc == 2: the wave's A rows are rows 0..127 of the W unit
+    int idle = 0;          // tall tile, wc == 3: no region of the tile
 
     f32x4 acc[2][4][4];
     u32x4 afr[4], afr2[4], wfr[4];
@@ -734,7 +772,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
     auto wait_mode = [&](int g, bool after_epilogue) -> int {      // 0: vmcnt(0), 1: vmcnt(4), 2: 4 + OPS_A, 3: 4 + OPS_B
         const bool a2 = 2 * g + 4 <= 2 * total - 1;                   // A(g+2) exists
         int m = a2 ? 1 : 0;
-        if (after_epilogue) m = (PAIR_OK && epi_ops != 0 && a2) ? (epi_ops == OPS_A ? 2 : 3) : 0;
+        if (after_epilogue && epi_ops != -2) m = (PAIR_OK && epi_ops != 0 && a2) ? (epi_ops == OPS_A ? 2 : 3) : 0;
         return m;
     };
     auto wait_next_slab = [&](int mode) {
@@ -752,8 +790,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
     asm volatile("s_mov_b32 %0, %1" : "=s"(is_g1) : "s"(grp));
     int g = 0;             // index of the slab being consumed (0..total-1)
     for (int t = blockIdx.x; t < nb; t += gridDim.x) {
-        int m0, n0;
-        tile_origin(t, m0, n0);
+        int m0, n0, kind;
+        tile_origin(t, m0, n0, kind);
+        {
+            // the wave's 128 x 64 region of the tile: whole tile (group -> rows, wc -> columns), tall tile (wc -> rows, group -> columns)
+            const int rg = kind != 0 ? wc : grp, cg = kind != 0 ? grp : wc;
+            asm volatile("s_mov_b32 %0, %1" : "=s"(a_in_w) : "s"(__builtin_amdgcn_readfirstlane((int)(kind != 0 && wc == 2))));
+            asm volatile("s_mov_b32 %0, %1" : "=s"(idle) : "s"(__builtin_amdgcn_readfirstlane((int)(kind != 0 && wc == 3))));
+            a_off = ((kind != 0 && wc >= 2) ? 0 : rg * 128) * ROW4 + foff;
+            w_off = (kind != 0 ? 128 + cg * 64 : cg * 64) * ROW4 + foff;
+            m0 += rg * 128;
+            n0 += cg * 64;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -778,8 +826,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
         auto slab = [&](auto steady_tag, auto last_tag, const int ks) __attribute__((always_inline)) {
             constexpr bool STEADY = decltype(steady_tag)::value;
             constexpr bool LAST = decltype(last_tag)::value;      // last slab of the tile: its closing barrier belongs to the tile end below
-            const char* ua = smem + ra * UNIT4;
             const char* uw = smem + rw * UNIT4;
+            const char* ua = a_in_w ? uw : smem + ra * UNIT4;
             int wm_l1 = 4, wm_c1 = 4;
             if constexpr (!STEADY) {
                 const int wmode = wait_mode(g, ks == 0 && g > 0);
@@ -815,8 +863,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
                 KSTAMP4(half * 6 + 0);
                 __builtin_amdgcn_s_barrier();
                 KSTAMP4(half * 6 + 1);
-                // ---- C segment: 32 MFMAs ----
+                // ---- C segment: 32 MFMAs (none in the two waves a tall tile leaves without a region) ----
                 __builtin_amdgcn_s_setprio(1);
+                if (!idle) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -834,6 +883,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
                     for (int ni = 0; ni < 4; ++ni)
                         acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, wfr[ni]), __builtin_bit_cast(bf16x8, afr2[mi]), acc[1][mi][ni], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 KSTAMP4(half * 6 + 3);
                 if (half == 1) {
@@ -873,12 +923,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
         if (grp == 0 || p.epi_serial) __builtin_amdgcn_s_barrier();
         issue_w();
         pre_issued = true;
-        const int ops = epilogue_wave_pair<T, EPI>(p.epi, m0 + grp * 128, n0 + wc * 64, p.M, p.N, lane, acc[0], acc[1]);
+        int ops = -2;      // -2: this wave had no region (tall tile) and issued nothing
+        if (!idle) ops = epilogue_wave_pair<T, EPI>(p.epi, m0, n0, p.M, p.N, lane, acc[0], acc[1]);
         if (grp == 1 && !p.epi_serial) __builtin_amdgcn_s_barrier();
 #ifdef COGS_EPI_CONSERVATIVE
-        epi_ops = 0; (void)ops;
+        epi_ops = ops == -2 ? -2 : 0;
 #else
-        epi_ops = __builtin_amdgcn_readfirstlane(ops > 0 ? ops : 0);
+        epi_ops = __builtin_amdgcn_readfirstlane(ops > 0 || ops == -2 ? ops : 0);
 #endif
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
@@ -1075,11 +1126,32 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         p.nbn = (g.N + BN3 - 1) / BN3;
         const bool env_nostore = g_cogs_debug.gemm_nostore != 0;
         const bool env_nolut = g_cogs_debug.gemm_rope_lut == 0;
+        // Tall tiles for a ragged column block of <= 128 columns (whole-line kernel only; see TALL4): p.nbn then counts the
+        // whole column blocks, and a group of the walk must be a whole number of 384-row tiles.
+        const int ragged_cols = g.N % BN3;
+        const bool tall = g_cogs_debug.gemm_tall != 0 && pp64_enabled() && g.K >= 128 && g.N > BN3 && ragged_cols > 0 &&
+                          ragged_cols <= 128;
+        if (tall) p.nbn = g.N / BN3;
         // tile walk: groups of group_m row blocks x all column blocks. Measured (in-run A/B, cfg2 shapes): few column
         // blocks with a long K (fc2: 5 x K 4352) want small groups (2: 0.627 -> 0.591 ms), many column blocks with a
         // short K (fc1: 17 x K 1152) want 8 (2: +7 %)
         const int env_gm = (int)g_cogs_debug.gemm_group_m;
-        p.group_m = env_gm > 0 ? env_gm : ((p.nbn <= 6 && g.K >= 2048) ? 2 : GROUP_M);
+        const bool few_cols_long_k = (g.N + BN3 - 1) / BN3 <= 6 && g.K >= 2048;
+        p.group_m = env_gm > 0 ? env_gm : (few_cols_long_k ? 2 : GROUP_M);
+        if (tall) p.group_m = env_gm > 0 ? (env_gm + 2) / 3 * 3 : (few_cols_long_k ? 3 : 6);
+        p.cf = p.group_m * p.nbn + (tall ? p.group_m * BM3 / TALL4 : 0);
+        // tiles of the first `rows` rows (a whole number of row blocks, or all of M)
+        auto count_tiles = [&](int rows) {
+            const int nbm = (rows + BM3 - 1) / BM3;
+            const int full = nbm / p.group_m, last = nbm % p.group_m;
+            int n = full * p.cf + last * p.nbn;
+            if (tall && last) n += (rows - full * p.group_m * BM3 + TALL4 - 1) / TALL4;
+            return n;
+        };
+        // row blocks (with tall tiles: a multiple of three = whole tall tiles) whose tiles number at most `tiles`
+        auto whole_blocks = [&](int tiles) {
+            return tall ? tiles * 3 / (3 * p.nbn + 2) / 3 * 3 : tiles / p.nbn;
+        };
         int pp_mask = cogs_epi_mask(g);
         p.rope_lut = nullptr; p.rope_lut_bytes = 0;
         if ((pp_mask & ~EPI_LNFOLD) == (EPI_BIAS | EPI_ROPE) && g.rope_lut && g.rope_rowpos && !g.rope_sin && !env_nolut && !pp64_enabled()) {
@@ -1096,7 +1168,8 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
         // whose half-size tiles fill the chip again (rows are independent: same arithmetic per row, same K order, so
         // a row's result does not depend on which kernel computed it).
         const bool env_nosplit = g_cogs_debug.gemm_split == 0;
-        const int nb = p.nbm * p.nbn;
+        const int nb = count_tiles(g.M);
+        p.ntiles = nb;
         const int rounds = nb / PERSISTENT_WGS, rem = nb % PERSISTENT_WGS;
         int mb_main = -1;      // >= 0: row blocks that stay in this kernel (0 = none: the whole GEMM goes to the ring kernel)
         // (calibrated on K = 1152 .. 4352, the ViT shapes; longer K -- the Qwen2 prompt pass at M = 2048 -- keeps the
@@ -1125,7 +1198,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
             float best = cost_pp;
             if (cost_ring < best) { best = cost_ring; mb_main = 0; }
             if (S == 1 && rounds == 1 && rem > 0) {
-                const int mb = PERSISTENT_WGS / p.nbn;                 // whole row blocks inside the first round
+                const int mb = whole_blocks(PERSISTENT_WGS);           // whole row blocks inside the first round
                 const int rows_rem = g.M - mb * BM3;
                 if (mb > 0 && rows_rem >= 512) {     // the remainder must reach the 256x128 ring kernel the cost model prices
                     const float cost_split = 1.f + c_ring * launch_cost(((rows_rem + BM2 - 1) / BM2) * rbn) + c_launch;
@@ -1136,7 +1209,7 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
             // (many tiles: pays when a tile is long against a second launch and the last round is less than ~45 % full:
             // measured with the two-segment K loop at K = 1152: -2 %; K = 3584, last round 34 % full: +2 %; K = 18944,
             // 34 %: +6 %; K = 4352, 51 % full (ViT fc2): -2 %, so it no longer splits)
-            const int mb = rounds * PERSISTENT_WGS / p.nbn;          // whole row blocks within the full rounds
+            const int mb = whole_blocks(rounds * PERSISTENT_WGS);    // whole row blocks within the full rounds
             if (mb > 0 && g.M - mb * BM3 >= 512) mb_main = mb;
         }
         const bool env_choice = g_cogs_debug.gemm_choice != 0;      // diagnostics: which body each shape gets
@@ -1158,7 +1231,8 @@ int cogs_k_gemm(hipStream_t st, const CogsGemm& g) {
             }
             if (mb_main > 0) {
                 p.M = rows_main; p.nbm = mb_main;
-                dispatch_pp(st, p, p.nbm * p.nbn, pp_mask);
+                p.ntiles = count_tiles(rows_main);
+                dispatch_pp(st, p, p.ntiles, pp_mask);
                 const int rc2 = COGS_LAUNCH_CHECK();
                 if (rc2 != COGS_OK) return rc2;
             }

@@ -620,6 +620,70 @@ def test_whole_line_gemm_equals_the_k_tile_gemm_bit_for_bit(dev):
         assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
 
 
+def test_tall_ragged_column_tiles_equal_padded_tiles_bit_for_bit(dev):
+    """Round 6: gemm_tn_pp64_kernel walks a ragged column block of <= 128 columns (N = 1152: 4.5 blocks of 256, N = 3456:
+    13.5) as tiles of 384 rows x 128 columns through the same LDS ring (csrc/gemm.hip, TALL4) instead of a half-empty 256 x 256
+    tile. Every output element keeps its MFMAs and its K order, so the results must be the bits of the padded walk (debug switch
+    gemm_tall = 0). Shapes: row counts that are / are not multiples of 384 and of 256, fewer rows than one tall tile's second
+    and third row group, a ragged block narrower than 128 columns (generic epilogue in its second column group), every fused
+    ViT epilogue of an N = 1152 / 3456 GEMM (bias + residual + row statistics, rotary + head-major), walk groups forced to
+    3 / 6 / 9 row blocks, and the few-tile split choices of a frame-sharded share (gemm_split)."""
+    from cogstream_amd import _lib as L2
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(17)
+    rnd = lambda *s: (torch.randn(*s, generator=g, device=dev) * 0.5).bfloat16()
+    hd, H, I = 72, 1152, 4352
+
+    def both(tag, **kw):
+        outs = []
+        for tall in (1, 0):
+            with L2.debug_switch("gemm_tall", tall):
+                rs = kw.get("row_stats")
+                if rs is not None:
+                    rs.fill_(-7.0)
+                o = ops.gemm(**kw).clone()
+                body = L2.debug_get("gemm_last_body")
+                outs.append((o, None if rs is None else rs.clone(), body))
+        torch.cuda.synchronize()
+        (a, sa, ba), (b, sb, bb) = outs
+        assert torch.equal(a, b), (tag, ba, bb, float((a.float() - b.float()).abs().max()))
+        if sa is not None:
+            assert torch.equal(sa, sb), (tag, "row statistics")
+        return ba
+
+    bodies = set()
+    for M in (59136 // 4, 59136 // 4 + 40, 7392, 6400, 1024, 1280 + 8, 1536, 3 * 384 + 130, 2049):
+        x, big = rnd(M, H), rnd(M, I)
+        nf = hd // 4
+        hpos = torch.randint(0, 22, (M,), generator=g, device=dev)
+        wpos = torch.randint(0, 42, (M,), generator=g, device=dev)
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(nf, dtype=torch.float32, device=dev) / nf))
+        ang = torch.cat([hpos[:, None].float() * inv_freq, wpos[:, None].float() * inv_freq], 1)
+        table = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+        stats = torch.empty(M, H // 64, 2, device=dev, dtype=torch.float32)
+        ln_ab = torch.rand(M, 2, generator=g, device=dev) + 0.5
+        col_c = torch.randn(3 * H, generator=g, device=dev)
+        cases = [
+            ("out-proj + residual + statistics", dict(a=x, w=rnd(H, H), bias=rnd(H), residual=rnd(M, H), row_stats=stats)),
+            ("fc2 + residual + statistics", dict(a=big, w=rnd(H, I), bias=rnd(H), residual=rnd(M, H), row_stats=stats)),
+            ("qkv + rotary, head-major, LN fold", dict(a=x, w=rnd(3 * H, H), rope_cos=table, rope_cols=2 * H, head_dim=hd,
+                                                       ln_ab=ln_ab, col_c=col_c, hm_cols=H)),
+            ("qkv + rotary, row-major", dict(a=x, w=rnd(3 * H, H), bias=rnd(3 * H), rope_cos=table, rope_cols=2 * H, head_dim=hd)),
+            ("plain, 1.5 column blocks", dict(a=x, w=rnd(384, H))),
+            ("plain, ragged block of 76 columns", dict(a=x, w=rnd(1100, H), bias=rnd(1100))),
+            ("K = 128 (two slabs)", dict(a=rnd(M, 128), w=rnd(H, 128))),
+        ]
+        for name, kw in cases:
+            bodies.add(both((M, name), **kw))
+        for gm in (3, 4, 9):
+            with L2.debug_switch("gemm_group_m", gm):
+                bodies.add(both((M, "group_m", gm), **cases[0][1]))
+        with L2.debug_switch("gemm_split", 0):
+            bodies.add(both((M, "unsplit"), **cases[0][1]))
+            bodies.add(both((M, "unsplit fc2"), **cases[1][1]))
+    assert 4 in bodies, bodies          # the whole-line kernel (and with it the tall walk) did run
+
+
 def test_ping_pong_prompt_attention_equals_the_shipped_kernel_bit_for_bit(dev):
     """attn_prefill_pp_kernel (round 4, off by default: debug switch attn_prefill_pp = 1) runs the arithmetic of
     attn_prefill_dma_kernel<0> (the round-4 kernel: debug switch attn_prefill_deep = 0) in a different schedule (256 query rows per workgroup, two wave groups half a tile apart,
