@@ -455,8 +455,9 @@ def main() -> None:
     ap.add_argument("--no-session", action="store_true", help="skip the configs[3] multi-turn session timing")
     ap.add_argument("--debug", default="", help="library debug switches for A/B runs: name=value[,name=value...] "
                                                 "(cogs_debug_set; `python -c 'from cogstream_amd import _lib; print(_lib.debug_list())'`)")
-    ap.add_argument("--vit-streams", type=int, default=2, choices=[1, 2],
-                    help="1: encode every clip on one stream (per-kernel profiles); 2 (default): two frame halves on two streams")
+    ap.add_argument("--vit-streams", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="1: encode every clip on one stream (per-kernel profiles); 2 (default): two frame halves on two streams; "
+                         "3 / 4: as many contiguous frame ranges (cogs_vit_set_streams; profiles/r5_vit_streams_1to4.txt)")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: LayerNorm as its own kernel instead of folded into the GEMMs")
     ap.add_argument("--emulate-shard", type=int, default=8,
                     help="N = 1 only: also time ONE rank's share (1/R of the frames) of the clip on this GPU and report "

@@ -153,11 +153,28 @@ const char* cogs_status_string(cogs_status s) {
     }
 }
 
-const char* cogs_version(void) { return "cogstream_amd 0.1 (gfx950)"; }
+const char* cogs_version(void) { return "cogstream_amd 0.2 (gfx950)"; }     // 0.2: cogs_gemm_desc.hm_rows / hm_cols, cogs_attn_desc.head_stride
 
 // ---------------------------------------------------------------- diagnostics (csrc/debug.h)
+// accepted range of a switch: on / off unless listed here
+static bool cogs_debug_value_ok(const char* name, int64_t v) {
+    struct Range { const char* name; int64_t lo, hi; };
+    static const Range ranges[] = {
+        {"gemm_wgs", 0, 256}, {"gemm_pad_pct", 100, 400}, {"gemm_group_m", 0, 64}, {"gemm_co_streams", 0, 8},
+        {"gemm_ring_cost_permille", 1, 4000}, {"gemv_small_n", 0, 1 << 30}, {"attn_vit", 0, 2}, {"attn_prio", 0, 2},
+        {"attn_nq", 0, 2}, {"vit_split_max", 0, INT64_MAX}, {"llm_split_keys", 0, 1 << 24}, {"km_row_groups", 0, 1 << 16},
+    };
+    for (const Range& r : ranges)
+        if (strcmp(name, r.name) == 0) return v >= r.lo && v <= r.hi;
+    return v == 0 || v == 1;
+}
+
 cogs_status cogs_debug_set(const char* name, int64_t value) {
     if (!name) return COGS_E_INVALID;
+    if (!cogs_debug_value_ok(name, value)) return COGS_E_INVALID;
+    if (value != 0 && (strcmp(name, "gemm_nostore") == 0 || strcmp(name, "gemm_trace") == 0))
+        fprintf(stderr, "[cogs] debug switch %s = %lld: a timing / tracing mode -- cogs_gemm %s until it is set back to 0\n", name,
+                (long long)value, strcmp(name, "gemm_nostore") == 0 ? "does NOT write its result" : "synchronises and prints per-tile stamps");
 #define COGS_DBG_SET(n, dflt, doc) if (strcmp(name, #n) == 0) { g_cogs_debug.n = value; return COGS_OK; }
     COGS_DEBUG_SWITCHES(COGS_DBG_SET)
 #undef COGS_DBG_SET
@@ -182,7 +199,7 @@ const char* cogs_debug_list(void) {
         "gemm_last_body (read only): body the last cogs_gemm dispatched to -- 1 128x128, 2 256x128 ring, 3 K-tile ping-pong, "
         "4 whole-line ping-pong, 5 ping-pong + ring (split launch), 6 GEMV\n"
         "attn_last_kernel (read only): kernel of the last cogs_attention -- 1 general MFMA, 2 ViT unpipelined, 3 ViT pipelined, "
-        "4 single-token decode, 5 prompt LDS-DMA, 6 prompt ping-pong, 7 row-wise fp32, 8 ViT pipelined on head-major K/V, 9 prompt kernel with 64 query rows per wave\n";
+        "4 single-token decode, 5 prompt LDS-DMA, 7 row-wise fp32, 8 ViT pipelined on head-major K/V\n";
 }
 
 cogs_status cogs_create(int device, cogs_handle* out) {

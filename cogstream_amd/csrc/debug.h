@@ -4,14 +4,19 @@
 // measurement tools (bench.py --debug, tools/*) and the A/B tests flip an entry by name, run, and flip it back -- in one
 // process, so both sides of a comparison run on the same device (rounds 1-4 read ~28 COGS_* environment variables into
 // function-local statics spread over the kernel files; a value could only be chosen before the first call).
-// The table is process-wide and unsynchronised: set a switch between calls, not beside a running call on another thread.
+// The table is process-wide. Its entries are relaxed atomics: another host thread driving its own handle may read a switch (or
+// write one of the two last_* reports) while this one sets it without a data race -- which value a call running at that moment
+// sees is still unspecified, so set a switch between calls. cogs_debug_set checks the value against the entry's range
+// (csrc/capi.hip) and warns on stderr when a timing-only switch that changes results is turned on.
 #pragma once
+#include <atomic>
 
 //   X(name, default, meaning)
 #define COGS_DEBUG_SWITCHES(X)                                                                                              \
     /* ---- GEMM (csrc/gemm.hip) ---- */                                                                                    \
     X(gemm_pp64, 1, "1: whole-line ping-pong kernel (gemm_tn_pp64_kernel); 0: the 32-wide K-tile body it replaced")         \
     X(gemm_tall, 1, "whole-line kernel: 1 a ragged column block of <= 128 columns as 384x128 tiles (round 6), 0 as padded 256x256 tiles") \
+    X(gemm_even_grid, 0, "whole-line kernel: 1 the fewest persistent workgroups that keep the round count (every workgroup the same number of tiles), 0 always 256") \
     X(gemm_pingpong, 1, "0: never take a ping-pong kernel (256x128 ring / 128x128 kernels only)")                          \
     X(gemm_small, 0, "1: always the 128x128 kernel")                                                                        \
     X(gemm_wgs, 256, "persistent workgroups of the 256x128 ring kernel (0: one tile per workgroup)")                        \
@@ -35,10 +40,7 @@
     X(attn_combine32, 1, "split-KV combine: 1 one block per (head, 32-column slice), 8 loads in flight per thread; 0 one block per head") \
     X(attn_prefill_dma, 1, "0: Qwen2 prompt attention through the general register-staged kernel")                          \
     X(attn_prefill_deep, 1, "prompt LDS-DMA kernel: 1 fragment reads ordered 6-8 ahead of their MFMAs + running maximum deferred to 2^6 (round 5: 1.82 -> 1.64 ms), 0 the round-4 kernel") \
-    X(attn_prefill64, 0, "1: Qwen2 prompt attention with 64 query rows per wave, software-pipelined (round 5: correct, measured 2.94 vs 1.97 ms per layer -- off)") \
-    X(attn_prefill_pp, 0, "1: ping-pong form of the prompt attention (bit-identical, measured slower)")                     \
     X(attn_prio, 2, "prompt attention wave priorities: 0 none, 1 MFMA phases raised, 2 softmax phase raised")               \
-    X(attn_pp_prio, 1, "ping-pong prompt attention: 1 priority raised in the MFMA group")                                   \
     X(attn_light_first, 0, "1: causal query tiles issued lightest first")                                                   \
     X(attn_nq, 0, "general kernel: 1 / 2 forces 16 / 32 query rows per wave")                                              \
     /* ---- encoder / LLM drivers (csrc/capi.hip), k-means ---- */                                                          \
@@ -47,14 +49,15 @@
     X(km_row_groups, 0, "> 0: row groups of the k-means distance pass (0: sized to fill the chip)")
 
 struct CogsDebug {
-#define COGS_DBG_FIELD(name, dflt, doc) long long name = dflt;
+#define COGS_DBG_FIELD(name, dflt, doc) std::atomic<long long> name{dflt};
     COGS_DEBUG_SWITCHES(COGS_DBG_FIELD)
 #undef COGS_DBG_FIELD
     // read-only reports (cogs_debug_get): what the last cogs_gemm of this process dispatched to
     // 0 none yet, 1 128x128, 2 256x128 ring, 3 K-tile ping-pong, 4 whole-line ping-pong, 5 ping-pong + ring (split), 6 GEMV
-    long long gemm_last_body = 0;
+    std::atomic<long long> gemm_last_body{0};
     // ... and the last cogs_attention: 1 general MFMA kernel, 2 ViT unpipelined, 3 ViT pipelined (row-major K/V), 4 single-token
-    // decode (+ combine), 5 prompt LDS-DMA kernel, 6 prompt ping-pong kernel, 7 row-wise fp32 kernel, 8 ViT pipelined, head-major K/V, 9 prompt kernel with 64 rows per wave
-    long long attn_last_kernel = 0;
+    // decode (+ combine), 5 prompt LDS-DMA kernel, 7 row-wise fp32 kernel, 8 ViT pipelined, head-major K/V (6 and 9 were the archived
+    // ping-pong / 64-rows-per-wave prompt kernels: tools/experiments/attn_prefill_variants.hip)
+    std::atomic<long long> attn_last_kernel{0};
 };
 extern CogsDebug g_cogs_debug;     // capi.hip

@@ -975,6 +975,17 @@ void launch_big(hipStream_t st, const GemmArgs& p, int grid) {
 // (every epilogue but the rotary LUT one, for which it has no LDS left -- cogs_k_gemm then takes the rotary factors from
 // global memory instead: measured 1 % faster end to end than the LUT epilogue on the old body)
 bool pp64_enabled() { return g_cogs_debug.gemm_pp64 != 0; }
+// Persistent workgroups of the whole-line kernel for `tiles` tiles. 256 = one per CU; debug switch gemm_even_grid = 1: the
+// fewest workgroups (a multiple of 8: the tile walk is XCD-aware) that still finish in ceil(tiles / 256) rounds, so that every
+// workgroup walks the same number of tiles and the CUs the last round would leave idle are free from the start -- for the
+// other stream's kernel, or for the clock.
+int pp64_grid(int tiles) {
+    if (tiles <= PERSISTENT_WGS) return tiles;
+    if (g_cogs_debug.gemm_even_grid == 0) return PERSISTENT_WGS;
+    const int rounds = (tiles + PERSISTENT_WGS - 1) / PERSISTENT_WGS;
+    const int wgs = ((tiles + rounds - 1) / rounds + 7) / 8 * 8;
+    return wgs < PERSISTENT_WGS ? wgs : PERSISTENT_WGS;
+}
 template <int EPI>
 void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
     const size_t lds = RING3 * SLOT3 + ((EPI & EPI_ROPE_LUT) ? 28 * 1024 : 0);   // ring (+ rotary LUT, <= 28 KiB)
@@ -1033,7 +1044,7 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
             static std::atomic<uint64_t> attr_done64{0};
             cogs_ensure_dyn_lds((const void*)gemm_tn_pp64_kernel<EPI>, RING4 * UNIT4, attr_done64);
             g_cogs_debug.gemm_last_body = 4;
-            hipLaunchKernelGGL((gemm_tn_pp64_kernel<EPI>), dim3(grid < PERSISTENT_WGS ? grid : PERSISTENT_WGS), dim3(512), RING4 * UNIT4, st, p);
+            hipLaunchKernelGGL((gemm_tn_pp64_kernel<EPI>), dim3(pp64_grid(grid)), dim3(512), RING4 * UNIT4, st, p);
             return;
         }
     }

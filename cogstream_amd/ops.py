@@ -84,8 +84,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hq: int, hkv
     are [heads, L, hd] instead (cogs_attn_desc.head_stride; the output stays token-major). lib: another build of the
     library (tests: A/B identity)"""
     _need_cuda(q, k, v)
-    if head_major:
-        assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and q.dim() == 3
+    if head_major:       # [heads, L, hd] with contiguous (L, hd) blocks; the head stride may exceed L * hd (a view of a larger buffer)
+        assert q.dim() == 3 and all(t.stride(2) == 1 and (t.shape[1] == 1 or t.stride(1) == head_dim) for t in (q, k, v))
         Lq, Lk = q.shape[1], k.shape[1]
     else:
         Lq, Lk = q.shape[0], k.shape[0]
@@ -94,11 +94,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hq: int, hkv
     d = L.AttnDesc()
     d.dtype = dtype_code(q.dtype)
     d.Q, d.K, d.V, d.O = ptr(q), ptr(k), ptr(v), ptr(out)
-    if head_major:      # contiguous [heads, L, hd] tensors (strides of size-1 dimensions are not trusted)
+    if head_major:      # (strides of size-1 dimensions are not trusted: one head -> the dense stride)
         assert Lq == Lk and q.shape == k.shape == v.shape, "one head stride for q, k, v"
+        hs = [t.stride(0) if t.shape[0] > 1 else Lq * head_dim for t in (q, k, v)]
+        assert hs[0] == hs[1] == hs[2] >= Lq * head_dim, "one head stride for q, k, v"
         d.ldq = d.ldk = d.ldv = head_dim
         d.ldo = out.stride(0)
-        d.head_stride = Lq * head_dim
+        d.head_stride = hs[0]
     else:
         d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
         d.head_stride = 0

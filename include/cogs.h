@@ -86,6 +86,11 @@ const char* cogs_debug_list(void);
 
 /* ------------------------------------------------------------------ operator level ---- */
 
+/* DESCRIPTORS (cogs_gemm_desc, cogs_attn_desc, ...) MUST BE ZERO-INITIALISED before the caller fills in what it uses
+ * (`cogs_gemm_desc d = {0};` / memset / ctypes' default constructor): they carry no size or version member, new optional
+ * fields are appended at the end with 0 = "off" (round 5: cogs_gemm_desc.hm_rows / hm_cols, cogs_attn_desc.head_stride), and a
+ * field left holding stack garbage switches a feature on. cogs_version() names the ABI revision: "0.2" added those three. */
+
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T). nn.Linear / Conv2d(k=s=14) replacement
  * (model/modeling_videollama3_encoder.py:194-210,246-248,275,369-373; cogreasoner_chat.py:179-211).
  * K must be a multiple of 64 (bf16) / 32 (f32) -- pad with zeros; N a multiple of 4;

@@ -684,29 +684,43 @@ def test_tall_ragged_column_tiles_equal_padded_tiles_bit_for_bit(dev):
     assert 4 in bodies, bodies          # the whole-line kernel (and with it the tall walk) did run
 
 
-def test_ping_pong_prompt_attention_equals_the_shipped_kernel_bit_for_bit(dev):
-    """attn_prefill_pp_kernel (round 4, off by default: debug switch attn_prefill_pp = 1) runs the arithmetic of
-    attn_prefill_dma_kernel<0> (the round-4 kernel: debug switch attn_prefill_deep = 0) in a different schedule (256 query rows per workgroup, two wave groups half a tile apart,
-    the PV product of a tile one phase late, no skipped MFMAs on masked tiles): the outputs must be the same bits.
-    Whole prompt, ragged lengths (one group of the last block idle / partly filled), prefix-KV continuation (q_pos0)."""
+@pytest.mark.parametrize("variant", ["deep", "round4", "general", "general hd72"])
+def test_prescaled_attention_survives_a_key_far_above_the_running_reference(dev, variant):
+    """The deferred-maximum softmax of the pre-scaled kernels evaluates P = exp2(score - reference) against the reference it had
+    BEFORE the tile and rescales (O, l) afterwards; a key more than ~127 log2 units above everything a row has seen made P
+    infinite and the deferred factor turned it into inf * 0 = NaN (advisor finding, round 5). Such a tile now moves the
+    reference in front of its exponentials (PRE_FAR, csrc/attn.hip). One key in the middle of the sequence is scaled until
+    its scores reach +-400 log2 units: the output must be finite and as close to the fp32 softmax as without that key."""
     from cogstream_amd import _lib as L2
-    ops0 = _ops()
-    g = torch.Generator(device=dev).manual_seed(3)
-    hq, hkv, hd = 28, 4, 128
-    mk = lambda n, h: (torch.randn(n, h * hd, generator=g, device=dev) * 0.5).bfloat16()
-    alt = object()
-
-    class ops:
-        @staticmethod
-        def attention(*a, lib=None, **kw):
-            with L2.debug_switch("attn_prefill_deep", 0), L2.debug_switch("attn_prefill_pp", int(lib is not None)):
-                return ops0.attention(*a, **kw)
-    for S, pos0 in ((4096, 0), (2100, 0), (2433, 0), (300, 0), (1000, 1500)):
-        q, kk, v = mk(S, hq), mk(S + pos0, hkv), mk(S + pos0, hkv)
-        a = ops.attention(q, kk, v, hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True, q_pos0=pos0)
-        b = ops.attention(q, kk, v, hq=hq, hkv=hkv, head_dim=hd, causal=True, q_prescaled=True, q_pos0=pos0, lib=alt)
-        torch.cuda.synchronize()
-        assert torch.equal(a, b), (S, pos0, float((a.float() - b.float()).abs().max()))
+    ops = _ops()
+    hd = 72 if variant.endswith("hd72") else 128
+    hq, hkv = (4, 4) if hd == 72 else (28, 4)
+    S, far = 1100, 733
+    g = torch.Generator().manual_seed(S + hd)
+    q = (torch.randn(S, hq * hd, generator=g) * (LOG2E / math.sqrt(hd))).bfloat16()
+    k = torch.randn(S, hkv * hd, generator=g).bfloat16()
+    v = torch.randn(S, hkv * hd, generator=g).bfloat16()
+    k[far] *= 300.0
+    big = (q.float().view(S, hq, hd)[far:, :, :] * k.float().view(S, hkv, hd)[far].repeat_interleave(hq // hkv, 0)).sum(-1)
+    assert float(big.max()) > 160 and float(big.min()) < -160        # both signs, far beyond fp32's exponent range for exp2
+    sw = {"deep": {"attn_prefill_deep": 1}, "round4": {"attn_prefill_deep": 0}, "general": {"attn_prefill_dma": 0},
+          "general hd72": {}}[variant]
+    causal = hd == 128
+    import contextlib
+    with contextlib.ExitStack() as st:
+        for name, val in sw.items():
+            st.enter_context(L2.debug_switch(name, val))
+        if hd == 72:
+            st.enter_context(L2.debug_switch("attn_vit", 0))
+        kw = dict(hq=hq, hkv=hkv, head_dim=hd, causal=causal, q_prescaled=True)
+        if hd == 72:
+            kw.update(cu_seqlens=torch.tensor([0, S], dtype=torch.int32, device=dev), max_seqlen=S)
+        out = ops.attention(q.to(dev), k.to(dev), v.to(dev), **kw)
+        want = {"deep": 5, "round4": 5, "general": 1, "general hd72": 1}[variant]
+        assert L2.debug_get("attn_last_kernel") == want, L2.debug_get("attn_last_kernel")
+    assert torch.isfinite(out.float()).all(), "NaN / inf rows: %d" % int((~torch.isfinite(out.float())).any(1).sum())
+    ref = _attn_ref(q, k, v, hq, hkv, hd, causal=causal, scale=math.log(2.0))
+    assert rel_err(out.float(), ref) < 1.5e-2, rel_err(out.float(), ref)
 
 
 def test_round5_prompt_attention_kernel_is_as_close_to_fp32_as_the_round4_kernel(dev):
@@ -946,11 +960,20 @@ def test_attention_head_major_inputs_equal_token_major_bit_for_bit(dev, heads, l
                             max_seqlen=max(lens), q_prescaled=True)
         assert L.debug_get("attn_last_kernel") == (3 if variant == 2 else 2)
         hm3 = qkv.view(n, 3, heads, hd).permute(1, 2, 0, 3).contiguous()           # [3][heads][n][hd], one buffer
-        # poison everything around the buffer's rows the kernel may not read: a NaN pulled in from a neighbouring head or
-        # frame would survive the masked softmax as 0 * NaN
         out = ops.attention(hm3[0], hm3[1], hm3[2], hq=heads, hkv=heads, head_dim=hd, cu_seqlens=cu, max_seqlen=max(lens),
                             q_prescaled=True, head_major=True)
+        assert L.debug_get("attn_last_kernel") == (8 if variant == 2 else 2)
+        # the same with GUARD rows behind every head's rows (head stride = (n + 70) rows): a ragged last tile must repeat the
+        # segment's last row, never read on into what follows the head. The guards hold a huge FINITE value (the kernel file is
+        # built with -fno-honor-nans, so a NaN is no reliable tracer): one of them taken for a key would own its softmax row,
+        # one taken for a value would blow the output up
+        G = 70
+        guarded = torch.full((3, heads, n + G, hd), 3.0e38, device=dev, dtype=torch.bfloat16)
+        guarded[:, :, :n] = hm3
+        outg = ops.attention(guarded[0][:, :n], guarded[1][:, :n], guarded[2][:, :n], hq=heads, hkv=heads, head_dim=hd,
+                             cu_seqlens=cu, max_seqlen=max(lens), q_prescaled=True, head_major=True)
         assert L.debug_get("attn_last_kernel") == (8 if variant == 2 else 2)
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
     assert torch.equal(out, tok), float((out.float() - tok.float()).abs().max())
+    assert torch.equal(outg, tok), "guard rows behind a head's rows were read: %g" % float((outg.float() - tok.float()).abs().max())

@@ -2,7 +2,7 @@
 """Qwen2 prompt attention alone (hd 128, 28 query / 4 kv heads, causal, pre-scaled Q) at the bench's prompt length:
 python tools/attn_prefill_ab.py [S] [--debug attn_prefill_dma=0]. Every variant named on the command line is timed
 in THIS process, interleaved with the default (the LDS-DMA kernel attn_prefill_dma_kernel): attn_prefill_dma=0 is the
-register-staged general kernel (attn_fwd_bf16_kernel<128, 2, true>), attn_prefill_pp=1 the ping-pong form."""
+register-staged general kernel (attn_fwd_bf16_kernel<128, 2, true>), attn_prefill_deep=0 the round-4 form of the kernel."""
 import os
 import sys
 import time
