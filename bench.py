@@ -50,6 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+BARE_MFMA_TFLOPS = 2050.0     # measured, tools/micro/mfma_shape_dvfs.cpp on MI355X: 16x16x32 bf16, random operands, 1-2 waves per SIMD
 
 
 def vit_gemm_flops(n_patches: int, m_tokens: int, cfg, llm_hidden: int) -> float:
@@ -562,9 +563,9 @@ def main() -> None:
 
     def encode_step(clip, grid_full):
         """one step on this rank's frames of `clip` + the all-gather: projected tokens [M, 3584] on every rank"""
+        if wide or world == 1:      # encoder + projector as the product path runs them (chat._encode_project): one library call
+            return gather_tokens(enc.encode_project(clip["pix"], clip["grid_loc"], merge, proj)[1], grid_full, 2, world)
         tok = enc(clip["pix"], clip["grid_loc"], merge)
-        if wide or world == 1:
-            return gather_tokens(proj(tok), grid_full, 2, world)
         return proj(gather_tokens(tok, grid_full, 2, world))
 
     def step():
@@ -672,7 +673,7 @@ def main() -> None:
         # passes: FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction). The figure is read from the
         # PMC summary of the same command committed under profiles/ (tools/collect_profiles.sh), and labelled so.
         traffic, traffic_src = None, None
-        for name in ("r5_gemm_traffic.json", "r4_gemm_traffic.json", "r3_gemm_traffic.json", "r2_gemm_traffic.json", "r1_g_gemm_traffic.json"):
+        for name in ("r6_gemm_traffic.json", "r5_gemm_traffic.json", "r4_gemm_traffic.json", "r3_gemm_traffic.json", "r2_gemm_traffic.json", "r1_g_gemm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if world == 1 and T == 64 and not cfg3 and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")
@@ -684,7 +685,13 @@ def main() -> None:
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "launches": gemm_n, "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
-                           "flop_per_launch": gflops / max(gemm_n, 1)}
+                           "flop_per_launch": gflops / max(gemm_n, 1),
+                           # what a bare v_mfma_f32_16x16x32_bf16 loop on RANDOM operands delivers on this chip at the clock it
+                           # holds (2.09-2.20 GHz under that load; 2 480 on zeros at 2.39 GHz): profiles/r6_mfma_shape_dvfs.txt
+                           "bare_mfma_loop_tflops_random_data": BARE_MFMA_TFLOPS,
+                           "frac_of_bare_mfma_loop": round(ach / BARE_MFMA_TFLOPS, 4),
+                           "padding": "none since round 6 (MFMA busy cycles of the N = 1152 / 3456 GEMMs = their algorithmic "
+                                      "count: profiles/r6_b_pmc_mfma_busy.txt), so MFMA-busy IS useful utilisation"}
         attn_ms = float(ms[1])
         out["breakdown_ms"] = {"gemm": round(gemm_ms, 2), "attention": round(attn_ms, 2), "norm": round(float(ms[2]), 2),
                                "other": round(float(ms[3]), 2)}
@@ -709,7 +716,7 @@ def main() -> None:
         pf = gh_ * gw_
         px = pix_full[: t_sh * pf]
         g = torch.tensor([[t_sh, gh_, gw_]])
-        dt_sh = time_steps(lambda: proj(enc(px, g, merge)), max(5, min(4 * args.steps, 20)))
+        dt_sh = time_steps(lambda: enc.encode_project(px, g, merge, proj)[1], max(5, min(4 * args.steps, 20)))
         return {"ranks_emulated": R, "frames": t_sh, "patches": t_sh * pf, "ms_per_step": round(dt_sh * 1e3, 3),
                 "frames_per_s_one_rank": round(t_sh / dt_sh, 1),
                 "shard_efficiency": round((ms_full * 1e-3 / R) / dt_sh, 4),
@@ -793,10 +800,11 @@ def main() -> None:
                           (2.0 * S * 6.526e9 + 2.0 * S * S * lcfg.hidden_size * lcfg.num_hidden_layers / 2) / t_prefill / 1e12, 1),
                       "timing": "prefill and token loop timed separately, both after a full-size warm-up"}
         dtraffic, dsrc = None, None
-        dpath = os.path.join(ROOT, "profiles", "r3_decode_traffic.json")
-        if os.path.exists(dpath):       # fabric-side read bytes of one decode step, from a separate rocprofv3 --pmc pass
-            dtraffic = json.load(open(dpath)).get("fetch_bytes_per_token")
-            dsrc = ("committed PMC profile profiles/r3_decode_traffic.json (rocprofv3 --pmc FETCH_SIZE on tools/decode_trace.py "
+        dname = next((n for n in ("r6_decode_traffic.json", "r3_decode_traffic.json")
+                      if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        if dname:                       # fabric-side read bytes of one decode step, from a separate rocprofv3 --pmc pass
+            dtraffic = json.load(open(os.path.join(ROOT, "profiles", dname))).get("fetch_bytes_per_token")
+            dsrc = (f"committed PMC profile profiles/{dname} (rocprofv3 --pmc FETCH_SIZE on tools/decode_trace.py "
                     "at the same context, tools/decode_traffic.py; FETCH doubled per the gfx950 correction), not this run")
         out["decode"] = {"roofline": {"bound": "hbm", "bytes_per_token": int(bytes_per_token),
                                       "traffic": dtraffic, "traffic_source": dsrc,

@@ -171,6 +171,8 @@ SIGNATURES = {
                                 c_int, c_void_p, c_void_p, c_size_t]),
     "cogs_allgather_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "cogs_proj_load": (c_int, [c_void_p, C.POINTER(ProjWeights)]),
+    "cogs_vit_encode_project": (c_int, [c_void_p, c_void_p, c_void_p, c_int, C.POINTER(c_int64), C.POINTER(c_int64), c_int,
+                                        c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t]),
     "cogs_project": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t]),
     "cogs_llm_load": (c_int, [c_void_p, C.POINTER(LlmWeights)]),
     "cogs_llm_workspace_bytes": (c_int, [c_void_p, c_int, c_int, C.POINTER(c_size_t)]),

@@ -310,16 +310,17 @@ class CogReasoner:
         from .vision import REF_EAGER_GLOBAL
         sh = self._shard
         if sh is None or self.vision_encoder.attn_mode == REF_EAGER_GLOBAL:
-            return self.mm_projector(self.vision_encoder(pixel_values, grid_sizes, merge_sizes))
+            return self.vision_encoder.encode_project(pixel_values, grid_sizes, merge_sizes, self.mm_projector)[1]
         from .parallel import FramePlan, gather_rows
         plan = FramePlan(grid_sizes, merge_sizes, sh["world"])
         px, g, m = plan.local(pixel_values, sh["rank"])
         wide = sh["payload"] == "projected"
         width = self.mm_projector.packed.out_dim if wide else self.vision_encoder.cfg.hidden_size
         if g.shape[0]:
-            tok = self.vision_encoder(px, g, m)
             if wide:
-                tok = self.mm_projector(tok)
+                tok = self.vision_encoder.encode_project(px, g, m, self.mm_projector)[1]
+            else:
+                tok = self.vision_encoder(px, g, m)
         else:                                   # more ranks than frames: nothing to encode, still in the collective
             tok = torch.empty(0, width, device=self.device, dtype=self.dtype)
         self.last_debug.update(shard_pieces=plan.pieces[sh["rank"]], shard_tokens=plan.token_counts)

@@ -512,9 +512,12 @@ struct VitRange {
 // Not while the per-kernel profiler is on: overlapping launches stretch every bracket, so bench.py's `roofline` and
 // `breakdown_ms` describe the kernels one at a time. cogs_vit_set_streams(h, 1) or the debug switch vit_split_max switch it off.
 
-cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
-                            const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
-                            void* out_tokens, void* ws, size_t ws_bytes) {
+static cogs_status cogs_project_rows(cogs_handle h, hipStream_t st, const void* tokens, int M, void* out, void* ws);
+
+// proj_out != NULL: every frame range also runs the projector on its own tokens, on its own stream (cogs_vit_encode_project)
+static cogs_status vit_encode_impl(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
+                                   const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
+                                   void* out_tokens, void* ws, size_t ws_bytes, void* proj_out, void* proj_ws) {
     if (!h || !h->vit_ok || !pixel_values || !grid_sizes || !merge_sizes || V <= 0 || !out_tokens) return COGS_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     int64_t N = 0, nframes = 0;
@@ -530,7 +533,13 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
                    std::vector<int64_t>(merge_sizes, merge_sizes + V), attn_mode, out_tokens, ws, ws_bytes};
         COGS_TRY(r.begin());
         for (int l = 0; l < w.layers; ++l) COGS_TRY(r.layer(l));
-        return r.finish();
+        COGS_TRY(r.finish());
+        if (proj_out) {
+            int64_t toks = 0;
+            for (int v = 0; v < V; ++v) toks += grid_sizes[3 * v] * grid_sizes[3 * v + 1] * grid_sizes[3 * v + 2] / (merge_sizes[v] * merge_sizes[v]);
+            COGS_TRY(cogs_project_rows(h, st, out_tokens, (int)toks, proj_out, proj_ws));
+        }
+        return COGS_OK;
     };
     const int64_t split_max = g_cogs_debug.vit_split_max;
     int S = h->vit_streams;
@@ -539,6 +548,7 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
 
     // cut the frames into S contiguous runs at the frame boundaries nearest to r / S of the patches
     std::vector<VitRange> R;
+    std::vector<int64_t> tok_begin;                       // first token row of every range, then the total
     {
         std::vector<int64_t> frame_rows, frame_v;       // per frame: patches, video
         for (int v = 0; v < V; ++v)
@@ -555,6 +565,7 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
         cuts.push_back(nframes);
         size_t ws_off = 0;
         int64_t tok_off = 0;
+        tok_begin.clear();
         const size_t pes = pix_dtype == COGS_DT_BF16 ? 2 : 4;
         bool ok = ws != nullptr;
         for (int r = 0; r < S && ok; ++r) {
@@ -573,10 +584,12 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
             void *p0, *p1, *p2, *p3; float *q0, *q1; int32_t *i0, *i1, *i2;
             q.ws_bytes = vit_carve(w, rows, (int)(cuts[r + 1] - cuts[r]), c, &p0, &p1, &p2, &p3, &q0, &q1, &i0, &i1, &i2);
             ws_off += q.ws_bytes;
+            tok_begin.push_back(tok_off);
             tok_off += toks;
             ok = ws_off <= ws_bytes && rows > 0;
             R.push_back(std::move(q));
         }
+        tok_begin.push_back(tok_off);
         if (!ok) return whole();
     }
     while ((int)h->aux_streams.size() < S - 1) {          // streams and events of the handle, created once
@@ -603,11 +616,43 @@ cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel
     for (int l = 0; l < w.layers && rc == COGS_OK; ++l)
         for (int r = 0; r < S && rc == COGS_OK; ++r) rc = R[r].layer(l);
     for (int r = 0; r < S && rc == COGS_OK; ++r) rc = R[r].finish();
+    if (proj_out) {
+        // the projector's two GEMMs of a range run behind that range's encoder, on its stream: rows are independent, so the
+        // projected tokens are the bits cogs_project gives on the whole clip, and no range waits for the join to be projected
+        const size_t tes = (size_t)w.hidden * esize(w.dtype), pes2 = (size_t)h->proj.out_dim * esize(h->proj.dtype);
+        for (int r = 0; r < S && rc == COGS_OK; ++r)
+            rc = cogs_project_rows(h, R[r].st, (const char*)out_tokens + (size_t)tok_begin[r] * tes, (int)(tok_begin[r + 1] - tok_begin[r]),
+                                   (char*)proj_out + (size_t)tok_begin[r] * pes2, (char*)proj_ws + (size_t)tok_begin[r] * pes2);
+    }
     cogs_k_gemm_co_streams(1);
     // join unconditionally: the caller's stream must not run ahead of anything queued on the other ones
     for (int r = 1; r < S; ++r)
         if (hipEventRecord(h->ev_joins[r - 1], R[r].st) != hipSuccess || hipStreamWaitEvent(st, h->ev_joins[r - 1], 0) != hipSuccess) return COGS_E_HIP;
     return rc;
+}
+
+cogs_status cogs_vit_encode(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
+                            const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
+                            void* out_tokens, void* ws, size_t ws_bytes) {
+    return vit_encode_impl(h, stream, pixel_values, pix_dtype, grid_sizes, merge_sizes, V, attn_mode, out_tokens, ws, ws_bytes,
+                           nullptr, nullptr);
+}
+
+cogs_status cogs_vit_encode_project(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
+                                    const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
+                                    void* out_tokens, void* ws, size_t ws_bytes, void* proj_out, void* proj_ws,
+                                    size_t proj_ws_bytes) {
+    if (!h || !h->proj_ok || !h->vit_ok || !proj_out || !grid_sizes || !merge_sizes || V <= 0) return COGS_E_INVALID;
+    if (h->proj.in_dim != h->vit.hidden || h->proj.dtype != h->vit.dtype) return COGS_E_INVALID;
+    int64_t toks = 0;
+    for (int v = 0; v < V; ++v) {
+        const int64_t ms = merge_sizes[v];
+        if (ms <= 0) return COGS_E_INVALID;
+        toks += grid_sizes[3 * v] * grid_sizes[3 * v + 1] * grid_sizes[3 * v + 2] / (ms * ms);
+    }
+    if (!proj_ws || proj_ws_bytes < (size_t)toks * h->proj.out_dim * esize(h->proj.dtype)) return COGS_E_WORKSPACE;
+    return vit_encode_impl(h, stream, pixel_values, pix_dtype, grid_sizes, merge_sizes, V, attn_mode, out_tokens, ws, ws_bytes,
+                           proj_out, proj_ws);
 }
 
 cogs_status VitRange::begin() {
@@ -826,7 +871,13 @@ cogs_status cogs_project(cogs_handle h, cogs_stream stream, const void* tokens, 
     if (!h || !h->proj_ok || !tokens || !out || M <= 0) return COGS_E_INVALID;
     const cogs_proj_weights& w = h->proj;
     if (!ws || ws_bytes < (size_t)M * w.out_dim * esize(w.dtype)) return COGS_E_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
+    return cogs_project_rows(h, (hipStream_t)stream, tokens, M, out, ws);
+}
+
+// the projector's two GEMMs on M rows (arguments checked by the callers; ws holds M x out_dim elements)
+static cogs_status cogs_project_rows(cogs_handle h, hipStream_t st, const void* tokens, int M, void* out, void* ws) {
+    if (M <= 0) return COGS_OK;
+    const cogs_proj_weights& w = h->proj;
     CogsGemm g; g.dtype = w.dtype;
     g.A = tokens; g.lda = w.in_dim; g.W = w.w1; g.ldw = w.in_dim; g.C = ws; g.ldc = w.out_dim;
     g.bias = w.b1; g.M = M; g.N = w.out_dim; g.K = w.in_dim; g.act = COGS_ACT_GELU_ERF;

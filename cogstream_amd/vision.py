@@ -36,7 +36,7 @@ class VisionEncoder:
             L.lib.cogs_vit_load(self.handle.h, C.byref(self.packed.struct)), "cogs_vit_load"))
 
     def __call__(self, pixel_values: torch.Tensor, grid_sizes: torch.Tensor, merge_sizes: torch.Tensor,
-                 attn_mode=None) -> torch.Tensor:
+                 attn_mode=None, projector=None) -> torch.Tensor:
         if not pixel_values.is_cuda:
             raise L.CogsError("pixel_values must live on the GPU")
         self._activate()
@@ -54,11 +54,31 @@ class VisionEncoder:
         out = torch.empty(m, self.cfg.hidden_size, device=self.device, dtype=self.dtype)
         gsa = (C.c_int64 * len(gs))(*gs)
         msa = (C.c_int64 * len(ms))(*ms)
-        L.check(L.lib.cogs_vit_encode(self.handle.h, L.current_stream(), pixel_values.data_ptr(),
-                                      L.dtype_code(pixel_values.dtype), gsa, msa, V,
-                                      self.attn_mode if attn_mode is None else attn_mode, out.data_ptr(),
-                                      ws.data_ptr(), ws.numel()), "cogs_vit_encode")
-        return out
+        mode = self.attn_mode if attn_mode is None else attn_mode
+        if projector is None:
+            L.check(L.lib.cogs_vit_encode(self.handle.h, L.current_stream(), pixel_values.data_ptr(),
+                                          L.dtype_code(pixel_values.dtype), gsa, msa, V, mode, out.data_ptr(),
+                                          ws.data_ptr(), ws.numel()), "cogs_vit_encode")
+            return out
+        # encoder + projector in one call (cogs_vit_encode_project): every frame range projects its own tokens on its stream
+        if projector.handle is not self.handle or projector.dtype != self.dtype:
+            raise L.CogsError("encode_project: encoder and projector must share the device handle and the dtype")
+        projector._activate()
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        pws = self.handle.workspace("proj", m * projector.packed.out_dim * es)
+        pout = torch.empty(m, projector.packed.out_dim, device=self.device, dtype=self.dtype)
+        L.check(L.lib.cogs_vit_encode_project(self.handle.h, L.current_stream(), pixel_values.data_ptr(),
+                                              L.dtype_code(pixel_values.dtype), gsa, msa, V, mode, out.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), pout.data_ptr(), pws.data_ptr(), pws.numel()),
+                "cogs_vit_encode_project")
+        return out, pout
+
+    def encode_project(self, pixel_values: torch.Tensor, grid_sizes: torch.Tensor, merge_sizes: torch.Tensor, projector,
+                       attn_mode=None):
+        """(encoder tokens [M, hidden], projected tokens [M, out_dim]) = mm_projector(vision_encoder(...)) of
+        cogreasoner_chat.py:270-275 as one library call: the same bits as `projector(self(...))`, with every frame
+        range's projection queued on that range's stream"""
+        return self(pixel_values, grid_sizes, merge_sizes, attn_mode, projector=projector)
 
 
 class Projector:

@@ -368,6 +368,15 @@ typedef struct {
 cogs_status cogs_proj_load(cogs_handle h, const cogs_proj_weights* w);
 cogs_status cogs_project(cogs_handle h, cogs_stream stream, const void* tokens, int M, void* out, void* ws,
                          size_t ws_bytes /* >= M*out_dim elements */);
+/* encode_images (model/cogreasoner_chat.py:264-276: vision_encoder, then mm_projector) as ONE call: cogs_vit_encode with the
+ * projector's two GEMMs of every frame range queued behind that range's encoder on ITS stream, instead of on the caller's
+ * stream after the join (round 6: the ranges' projections overlap the other ranges' last layers). out_tokens [M, hidden] is
+ * still written (callers gather / cache the encoder tokens); proj_out [M, out_dim]; proj_ws >= M * out_dim elements.
+ * Results are the bits of cogs_vit_encode followed by cogs_project. */
+cogs_status cogs_vit_encode_project(cogs_handle h, cogs_stream stream, const void* pixel_values, int pix_dtype,
+                                    const int64_t* grid_sizes, const int64_t* merge_sizes, int V, int attn_mode,
+                                    void* out_tokens, void* ws, size_t ws_bytes, void* proj_out, void* proj_ws,
+                                    size_t proj_ws_bytes);
 
 /* ------------------------------------------------------------------------- Qwen2 ------ */
 

@@ -671,3 +671,30 @@ def test_content_key_of_gpu_resident_clips(dev):
     proc = pr.CogStreamProcessor(__import__("toy_tokenizer").ToyTokenizer(), device=dev)
     conv = [{"role": "user", "content": [{"type": "video", "video": clip, "timestamps": [0.0, 1, 2, 3, 4, 5]}, {"type": "text", "text": "q?"}]}]
     assert proc(conversation=conv)["video_keys"] == [k0]
+
+
+def test_encode_project_equals_encoder_then_projector_bit_for_bit(dev):
+    """cogs_vit_encode_project (round 6: every frame range projects its own tokens on its own stream) must give the bits of
+    cogs_vit_encode followed by cogs_project -- three videos of different grids in one call, 1 / 2 / 3 streams."""
+    from cogstream_amd import _lib as L
+    from cogstream_amd.vision import Projector, VisionEncoder
+    from cogstream_amd.weights import VisionConfig, random_proj_state, random_vit_state
+    vcfg = VisionConfig(hidden_size=576, intermediate_size=200, num_hidden_layers=3, num_attention_heads=8)
+    enc = VisionEncoder(random_vit_state(vcfg, seed=3, std=0.05), vcfg, dtype=torch.bfloat16, device=dev)
+    proj = Projector(random_proj_state(vcfg.hidden_size, 256, std=0.05), dtype=torch.bfloat16, device=dev)
+    grids = torch.tensor([[3, 4, 6], [5, 8, 8], [2, 10, 4]])
+    merges = torch.tensor([2, 2, 2])
+    n = int((grids[:, 0] * grids[:, 1] * grids[:, 2]).sum())
+    g = torch.Generator(device=dev).manual_seed(n)
+    pix = (torch.rand(n, 588, generator=g, device=dev) * 2 - 1).bfloat16()
+    try:
+        for s in (1, 2, 3):
+            L.check(L.lib.cogs_vit_set_streams(enc.handle.h, s))
+            tok = enc(pix, grids, merges)
+            want = proj(tok)
+            tok2, got = enc.encode_project(pix, grids, merges, proj)
+            torch.cuda.synchronize()
+            assert torch.equal(tok2, tok), s
+            assert torch.equal(got, want), (s, float((got.float() - want.float()).abs().max()))
+    finally:
+        L.check(L.lib.cogs_vit_set_streams(enc.handle.h, 2))

@@ -19,6 +19,7 @@ ap.add_argument("--frames", type=int, default=64)
 ap.add_argument("--grid", default="22x42")
 ap.add_argument("--streams", type=int, default=2)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--separate", action="store_true", help="projector as its own call behind the encoder (the form before round 6)")
 args = ap.parse_args()
 gh, gw = (int(v) for v in args.grid.split("x"))
 dev = torch.device("cuda:0")
@@ -34,6 +35,6 @@ for i in range(args.steps + 2):
     torch.cuda.synchronize()
     time.sleep(0.02)
     t0 = time.perf_counter()
-    o = proj(enc(pix, grid, merge))
+    o = enc.encode_project(pix, grid, merge, proj)[1] if not args.separate else proj(enc(pix, grid, merge))
     torch.cuda.synchronize()
     print(f"step {i}: {(time.perf_counter() - t0) * 1e3:.3f} ms {dbg}", flush=True)

@@ -26,6 +26,7 @@ ap.add_argument("--frames", type=int, default=64)
 ap.add_argument("--grid", default="22x42")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--separate", action="store_true", help="projector as its own call behind the encoder (the form before round 6)")
 ap.add_argument("--streams", type=int, default=2)
 ap.add_argument("specs", nargs="*")
 args = ap.parse_args()
@@ -41,8 +42,11 @@ grid, merge = torch.tensor([[T, gh, gw]]), torch.tensor([2])
 variants = [("default", {})] + [(s, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in s.split(","))) for s in args.specs]
 
 
+SEPARATE = [bool(args.separate)]      # the pseudo-switch separate=1 of a SPEC: projector as its own call behind the encoder
+
+
 def step():
-    return proj(enc(pix, grid, merge))
+    return enc.encode_project(pix, grid, merge, proj)[1] if not SEPARATE[0] else proj(enc(pix, grid, merge))
 
 
 class applied:
@@ -50,11 +54,16 @@ class applied:
         self.sw = sw
 
     def __enter__(self):
-        self.old = {k: L.debug_get(k) for k in self.sw}
+        self.sep = SEPARATE[0]
+        self.old = {k: L.debug_get(k) for k in self.sw if k != "separate"}
         for k, v in self.sw.items():
-            L.debug_set(k, v)
+            if k == "separate":
+                SEPARATE[0] = bool(v)
+            else:
+                L.debug_set(k, v)
 
     def __exit__(self, *a):
+        SEPARATE[0] = self.sep
         for k, v in self.old.items():
             L.debug_set(k, v)
 
