@@ -626,9 +626,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
 // is rows 0..255 of the tile as always; the "W unit" carries rows 256..383 of the tile in its rows 0..127 (staged by waves
 // 0..3) and the 128 weight rows in its rows 128..255 (waves 4..7). The 384 x 128 outputs are six 128 x 64 wave regions:
 // wave (group g, column wc) takes rows 128 wc.., columns 64 g.. for wc < 3 (wc == 2 reads its A fragments from the W unit),
-// and the two waves with wc == 3 -- one SIMD -- only stage and keep the barriers. Every output element still sees the same
-// MFMAs over the same K order, so a row's bits do not depend on which kind of tile produced it; three ragged half tiles
-// cost two tile times instead of three.
+// and the two waves with wc == 3 -- one SIMD -- stage, keep the barriers, run their MFMAs on unused data and skip the epilogue.
+// Every output element still sees the same MFMAs over the same K order, so a row's bits do not depend on which kind of tile
+// produced it; three ragged half tiles cost two tile times instead of three (MFMAs spent on padding: 3.7 % instead of 11.1 % of
+// the algorithmic count at N = 1152, 1.2 % instead of 3.7 % at N = 3456).
 constexpr int ROW4 = 128;                         // bytes per LDS row = 64 bf16 = one line of the operand
 constexpr int UNIT4 = 256 * ROW4;                 // 32 KiB: the A rows or the W rows of one slab
 constexpr int RING4 = 5;
@@ -863,9 +864,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
                 KSTAMP4(half * 6 + 0);
                 __builtin_amdgcn_s_barrier();
                 KSTAMP4(half * 6 + 1);
-                // ---- C segment: 32 MFMAs (none in the two waves a tall tile leaves without a region) ----
+                // ---- C segment: 32 MFMAs. (The two waves a tall tile leaves without a region run them too, on whatever their
+                // fragment reads returned, and drop the result: a run-time `if (!idle)` here -- one scalar branch in front of every
+                // MFMA block -- cost EVERY GEMM 2-6 % (profiles/r6_gemm_idle_branch_ab.txt), and the same choice made once per
+                // tile, around two copies of the K loop, made hipcc spill ~100 registers.) ----
                 __builtin_amdgcn_s_setprio(1);
-                if (!idle) {
+                {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll

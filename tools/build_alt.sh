@@ -8,8 +8,9 @@ python -m cogstream_amd.build > /dev/null
 B=cogstream_amd/csrc/build
 SRC=$1; shift
 EXTRA=""; [ "$SRC" = attn_vit ] && EXTRA="-fno-honor-nans"
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $EXTRA "$@" -c cogstream_amd/csrc/$SRC.hip -o $B/${SRC}_alt.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $EXTRA "$@" -c cogstream_amd/csrc/$SRC.hip -o $B/${SRC}_${ALT_NAME:-alt}.o
 objs=""
-for f in cogstream_amd/csrc/*.hip; do n=$(basename $f .hip); if [ $n = $SRC ]; then objs="$objs $B/${SRC}_alt.o"; else objs="$objs $B/$n.o"; fi; done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o cogstream_amd/libcogs_hip_alt.so $objs
-echo cogstream_amd/libcogs_hip_alt.so
+for f in cogstream_amd/csrc/*.hip; do n=$(basename $f .hip); if [ $n = $SRC ]; then objs="$objs $B/${SRC}_${ALT_NAME:-alt}.o"; else objs="$objs $B/$n.o"; fi; done
+OUT=cogstream_amd/libcogs_hip_${ALT_NAME:-alt}.so      # ALT_NAME=x: several alternatives side by side (tools/gemm_ab_lib.py x y ...)
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT $objs
+echo $OUT

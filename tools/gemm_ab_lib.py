@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Default library vs cogstream_amd/libcogs_hip_alt.so (tools/build_alt.sh) on the plain bf16 GEMM shapes of the path,
-interleaved in one process; results must be bit-identical."""
+"""Default library vs cogstream_amd/libcogs_hip_<name>.so (tools/build_alt.sh, ALT_NAME=<name>; default name: alt) on the bf16
+GEMM shapes of the path, interleaved in one process; results must be bit-identical.   python tools/gemm_ab_lib.py [name ...]"""
 import ctypes as C
 import os
 import sys
@@ -11,7 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogstream_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-alt = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cogstream_amd", "libcogs_hip_alt.so"))
+names = sys.argv[1:] or ["alt"]
+alts = [(n, C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cogstream_amd", f"libcogs_hip_{n}.so")))
+        for n in names]
 shapes = [("ViT qkv", 59136, 3456, 1152), ("ViT o", 59136, 1152, 1152), ("ViT fc1", 59136, 4352, 1152), ("ViT fc2", 59136, 1152, 4352),
           ("Qwen2 qkv", 15396, 4608, 3584), ("Qwen2 o", 15396, 3584, 3584), ("Qwen2 gate/up", 15396, 37888, 3584),
           ("Qwen2 down", 15396, 3584, 18944)]
@@ -20,9 +22,9 @@ for name, M, N, K in shapes:
     w = ((torch.rand(N, K, device=dev) * 2 - 1) * 0.05).bfloat16()
     bias = torch.rand(N, device=dev).bfloat16()
     res = torch.rand(M, N, device=dev).bfloat16() if (os.environ.get("AB_RESIDUAL") == "1" and N <= 4608) else None
-    outs, ts = {}, {"default": [], "alt": []}
+    outs, ts = {}, {n: [] for n in ["default"] + names}
     for r in range(7):
-        for tag, lib in (("default", None), ("alt", alt)):
+        for tag, lib in [("default", None)] + alts:
             out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -32,7 +34,10 @@ for name, M, N, K in shapes:
             if r:
                 ts[tag].append(e0.elapsed_time(e1))
             outs[tag] = out
-    same = bool(torch.equal(outs["default"], outs["alt"]))
-    md, ma = sorted(ts["default"])[3], sorted(ts["alt"])[3]
+    md = sorted(ts["default"])[3]
     fl = 2.0 * M * N * K
-    print(f"{name:14s} {M}x{N}x{K}: default {md:.3f} ms {fl / md / 1e9:6.0f} TF | alt {ma:.3f} ms {fl / ma / 1e9:6.0f} TF | alt/default {ma / md:.3f} | bit-identical {same}")
+    line = f"{name:14s} {M}x{N}x{K}: default {md:.3f} ms {fl / md / 1e9:6.0f} TF"
+    for n in names:
+        ma = sorted(ts[n])[3]
+        line += f" | {n} {ma:.3f} ms {fl / ma / 1e9:6.0f} TF, x{ma / md:.3f}, same bits {bool(torch.equal(outs['default'], outs[n]))}"
+    print(line, flush=True)
