@@ -711,7 +711,11 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             // canonicalising v_max in front of every chain): 17 -> 8 vector instructions per 32-key block on the port this
             // kernel is bound by (per tile and wave: 22 MFMA x 8 issue cycles + 32 v_exp x 8 + 16 v_cvt_pk + the maxima)
             const float d_own = own_max(sn);
+#ifdef AV_ABL_NORESCALE      // timing experiment (tools/attn_abl.sh): what does the rare path's wave vote + branch cost?
+            if (false) {
+#else
             if (__any(d_own > RESCALE_THR)) {
+#endif
                 // rare (wave-uniform): move the reference of the rows that need it; O, now complete up to block j, is
                 // multiplied by 2^-(m_new - sh) and S(j+1) is simply computed again with the new shift
                 const float d = pair_max(d_own);
