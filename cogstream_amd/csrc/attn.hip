@@ -31,6 +31,11 @@ namespace {
 // the reference BEFORE its exponentials instead of scaling (O, l) behind them (exp2 of the difference would overflow towards
 // inf, and inf * 2^-dd = NaN); up to 2^64 a row sum of 64 keys fits fp32 and P is exact in bf16
 constexpr float PRE_FAR = 64.f;
+#ifdef COGS_NO_PRE_FAR          // A/B builds only (tools/build_alt.sh attn -DCOGS_NO_PRE_FAR): what the far test costs
+#define COGS_PRE_FAR_ON false
+#else
+#define COGS_PRE_FAR_ON true
+#endif
 
 struct AttnArgs {
     const void* Q; const void* K; const void* V; void* O;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(128 * (4 / NQ), NQ == 1 ? 4 : ((PRE && HD == 72) ? 
                     m_ref[qi] = d0;
                     d = 0.f;
                 }
-                if (__any(d > PRE_FAR)) {
+                if (COGS_PRE_FAR_ON && __any(d > PRE_FAR)) {
                     // far above the reference (rare, wave-uniform): exp2(score - OLD reference) would overflow towards inf, and the
                     // factor applied afterwards would turn that into inf * 0 = NaN. Move the reference of those rows NOW: (O, l) take
                     // 2^-dd, the scores are shifted, and the test behind the exponentials finds nothing left to do for them
@@ -729,11 +734,17 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
                 m_ref[qi] = d0;
                 d = 0.f;
             }
-            if (__any(d > PRE_FAR)) {
-                // far above the reference (rare, wave-uniform; see the general kernel): the rows concerned move their reference in
-                // FRONT of the exponentials -- exp2(score - old reference) would be inf and the deferred factor would make it NaN
+            // DEEP (the shipped form): the reference only moves when a score exceeds it by 2^PREFILL_THR (P <= 2^6 until then: exact in
+            // fp32 sums, the same relative precision in bf16); the test is wave-uniform on the lanes' OWN maxima, so the two lane
+            // exchanges of colgroup_max and the rescale of O leave the common path (they ran in ~25 % of the tiles). Round 6: the move
+            // happens HERE, in front of the exponentials, for every threshold crossing -- one test per tile as before, and a key far
+            // above the reference can no longer make exp2 overflow before a deferred factor is applied (inf * 2^-dd = NaN).
+            // Round-4 form (DEEP = 0, A/B only): the deferred factor behind the PV product stays; only a crossing of more than
+            // 2^PRE_FAR takes this path.
+            constexpr float MOVE_THR = DEEP ? PREFILL_THR : PRE_FAR;
+            if (COGS_PRE_FAR_ON && __any(d > MOVE_THR)) {
                 const float dr = DEEP ? colgroup_max(d) : d;
-                const float dd = dr > PRE_FAR ? dr : 0.f;
+                const float dd = dr > MOVE_THR ? dr : 0.f;
                 const float al = __builtin_amdgcn_exp2f(-dd);
 #pragma unroll
                 for (int ut = 0; ut < 4; ++ut)
@@ -760,15 +771,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
                 }
             l_run[qi] += psum;
             if constexpr (DEEP) {
-                // the reference only moves when a score exceeds it by 2^PREFILL_THR (P <= 2^6 until then: exact in fp32 sums, the
-                // same relative precision in bf16); the test is wave-uniform on the lanes' OWN maxima, so the two lane
-                // exchanges of colgroup_max and the rescale of O leave the common path (they ran in ~25 % of the tiles)
-                if (__any(d > PREFILL_THR)) {
-                    const float dr = colgroup_max(d);
-                    const float dd = dr > PREFILL_THR ? dr : 0.f;
-                    post_alpha[qi] = __builtin_amdgcn_exp2f(-dd);
-                    m_ref[qi] += dd;
-                }
+                // (moved in front of the exponentials, above)
             } else if (__any(d > 0.f)) {
                 const float dd = fmaxf(d, 0.f);
                 post_alpha[qi] = __builtin_amdgcn_exp2f(-dd);
