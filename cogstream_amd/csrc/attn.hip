@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) oacc[d][qi] = f32x4{0, 0, 0, 0};
     float l_run[NQ], m_ref[NQ];
-    bool first_tile = true;
+    bool first_tile_rt = true;      // round-4 form (DEEP = 0) only
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) { l_run[qi] = 0.f; m_ref[qi] = 0.f; }
 
@@ -648,8 +648,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
 
     const bool wave_active = q0 + wid * 32 < qe;
 
-    auto process_tile = [&](const int kt, auto masked_tag) {
+    // first_tag: the wave's first tile (kt == 0: it subtracts its own maximum explicitly) -- a compile-time copy, so that the
+    // other tiles carry no `first tile?` test (DEEP only; the round-4 form keeps the run-time flag)
+    auto process_tile = [&](const int kt, auto masked_tag, auto first_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool FIRST_CT = decltype(first_tag)::value;
+        const bool first_tile = DEEP ? FIRST_CT : first_tile_rt;
         const char* Ks = smem + (kt & 1) * BUF;
         const char* Vs = Ks + K_LDS;
         if (!wave_active) return;
@@ -820,6 +824,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
 #endif
+        if constexpr (!DEEP) {        // the deferred factor exists in the round-4 form only
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
             if (__any(post_alpha[qi] != 1.f)) {
@@ -828,7 +833,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
                 for (int d = 0; d < DT; ++d) oacc[d][qi] *= post_alpha[qi];
             }
         }
-        first_tile = false;
+        }
+        first_tile_rt = false;
     };
 
 
@@ -864,16 +870,24 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
 #endif
 #endif
     };
-    for (int kt = 0; kt < t_mid; ++kt) {
+    int kt = 0;
+    if (nt > 0) {                                   // tile 0, the copy that sets the reference
+        if (1 < nt) issue_tile(1);
+        if (t_mid > 0) process_tile(0, std::false_type{}, std::true_type{});
+        else process_tile(0, std::true_type{}, std::true_type{});
+        tile_tail(0);
+        kt = 1;
+    }
+    for (; kt < t_mid; ++kt) {
 #ifndef PF_ABL_NOSYNC
         if (kt + 1 < nt) issue_tile(kt + 1);
 #endif
-        process_tile(kt, std::false_type{});
+        process_tile(kt, std::false_type{}, std::false_type{});
         tile_tail(kt);
     }
-    for (int kt = t_mid; kt < nt; ++kt) {
+    for (; kt < nt; ++kt) {
         if (kt + 1 < nt) issue_tile(kt + 1);
-        process_tile(kt, std::true_type{});
+        process_tile(kt, std::true_type{}, std::false_type{});
         tile_tail(kt);
     }
 
