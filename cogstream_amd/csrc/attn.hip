@@ -546,7 +546,9 @@ __device__ __forceinline__ int v_swz(int row) { return ((row & 3) | (((row >> 3)
 // would take 0.75 ms -- the two ADD: SQ_VALU_MFMA_BUSY_CYCLES + the VALU's active cycles are ~95 % of the resident time,
 // bank conflicts 0, LDS array 21 % busy, 2.4 % of wave time waiting for LDS.
 constexpr float PREFILL_THR = 6.f;
-template <int DEEP>
+// PRIO: the wave-priority scheme (debug switch attn_prio) as a compile-time choice -- 2 = raised in the softmax phase (shipped), -1 =
+// read p.prio_mode at run time (A/B runs: four s_cmp / s_cbranch pairs per tile, next to the MFMA blocks)
+template <int DEEP, int PRIO = -1>
 __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
     constexpr int HD = 128, NQ = 2, NT = 256, KS = 4, DT = 8;
     constexpr int K_LDS = 64 * 256, V_LDS = 64 * 256, BUF = K_LDS + V_LDS;     // 32 KiB per tile
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
         const int kbase = ks + kt * 64;
         const bool second_half = !MASKED || kbase + 32 < kend;
         f32x4 sacc[4][NQ];
-        if (p.prio_mode == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(0);
+        { const int pm = PRIO >= 0 ? PRIO : p.prio_mode; if (pm == 1) __builtin_amdgcn_s_setprio(1); else if (pm == 2) __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
         for (int ut = 0; ut < 4; ++ut) {
             if (MASKED && ut >= 2 && !second_half) {
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         }
 #endif
-        if (p.prio_mode == 1) __builtin_amdgcn_s_setprio(0); else if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(1);
+        { const int pm = PRIO >= 0 ? PRIO : p.prio_mode; if (pm == 1) __builtin_amdgcn_s_setprio(0); else if (pm == 2) __builtin_amdgcn_s_setprio(1); }
         bf16x8 pf[2][NQ];
         float post_alpha[NQ];
 #pragma unroll
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(AttnArgs p) {
                 pf[u][qi] = __builtin_bit_cast(bf16x8, w);
             }
         }
-        if (p.prio_mode == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(0);
+        { const int pm = PRIO >= 0 ? PRIO : p.prio_mode; if (pm == 1) __builtin_amdgcn_s_setprio(1); else if (pm == 2) __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
 #pragma unroll
@@ -1144,8 +1146,9 @@ int cogs_k_attention(hipStream_t st, const CogsAttn& a) {
             // (two more forms were built, tested at full size and measured slower -- a ping-pong form, 1.89 vs 1.81-1.86 ms per layer
             // at 15 395 tokens, and 64 query rows per wave, 2.94 vs 1.97 ms: tools/experiments/attn_prefill_variants.hip)
             g_cogs_debug.attn_last_kernel = 5;
-            if (g_cogs_debug.attn_prefill_deep) hipLaunchKernelGGL(attn_prefill_dma_kernel<1>, grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL(attn_prefill_dma_kernel<0>, grid, dim3(256), 0, st, p);
+            if (g_cogs_debug.attn_prefill_deep && p.prio_mode == 2) hipLaunchKernelGGL((attn_prefill_dma_kernel<1, 2>), grid, dim3(256), 0, st, p);
+            else if (g_cogs_debug.attn_prefill_deep) hipLaunchKernelGGL((attn_prefill_dma_kernel<1, -1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((attn_prefill_dma_kernel<0, -1>), grid, dim3(256), 0, st, p);
         } else if (a.head_dim == 128 && a.q_len == 1 && p.nsplit > 1 && p.gqa_pack && pre && !env_old_dec) {
             const int rc = cogs_k_attention_decode(st, a, p.part_o, p.part_ml);
             if (rc != COGS_OK) return rc;
