@@ -522,11 +522,24 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         if (wid == 1) dma16(vb, off[NPI], st + TILE + 8 * 1024);
     };
     // this wave's pieces of every tile but the `newer` most recently issued ones have landed (n_own = 2 NPI or 2 NPI + 1)
+#ifdef AV_OLD_BRANCHES      // A/B builds (tools/attn_abl.sh): the round-5 control flow of the tile loop
     auto wait_tiles = [&](int newer) {
         if (newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (newer == 1) { if (n_own == 2 * NPI + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPI + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPI) : "memory"); }
         else { if (n_own == 2 * NPI + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NPI + 2) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NPI) : "memory"); }
     };
+#else
+    // Round 6: ONE immediate per case for all four waves -- the count of the waves that issue 2 NPI pieces per tile. The two waves
+    // with an extra piece then also wait for the oldest piece of the next-but-one tile (issued a whole tile earlier: landed), and
+    // the tile loop loses a wave-dependent branch in front of its barrier (a scalar branch next to an MFMA block costs percent:
+    // profiles/r6_gemm_idle_branch_ab.txt, r6_prefill_attn_branches_ab.txt).
+    (void)n_own;
+    auto wait_tiles = [&](int newer) {
+        if (newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NPI) : "memory");
+    };
+#endif
 
 #ifndef AV_LATE_ISSUE
     // Round 5: tile 0 goes out HERE, as soon as its addresses exist -- in front of the ~800 cycles of per-lane read offsets,
@@ -736,17 +749,24 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #ifdef COGS_PHASE_STAMPS
     unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    auto tile_head = [&](const int t, auto slot_tag) {       // slot_tag: ring slot of tile t when known at compile time, else -1
+    // slot_tag: ring slot of tile t when known at compile time, else -1; steady_tag: tiles t + 2 and t + 3 are known to exist (the
+    // unrolled main loop), so neither the wait nor the issue is behind a run-time test
+    auto tile_head = [&](const int t, auto slot_tag, auto steady_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
+#ifdef AV_OLD_BRANCHES
+        constexpr bool STEADY = false;
+#else
+        constexpr bool STEADY = decltype(steady_tag)::value;
+#endif
         // outstanding, oldest first: tile t+1 (if any), tile t+2 (if any); tile t+1 must have landed
         unsigned long long h0 = 0, h1 = 0, h2 = 0, h3 = 0;
         PHT(h0);
-        wait_tiles(t + 2 < nt ? 1 : 0);
+        if constexpr (STEADY) wait_tiles(1); else wait_tiles(t + 2 < nt ? 1 : 0);
         PHT(h1);
         __builtin_amdgcn_s_barrier();     // K(t+1), V(t) visible to all; slot of tile t-1 no longer read by anyone
         PHT(h2);
 #ifndef ABL_NOLOAD
-        if (t + 3 < nt) issue_tile(t + 3, SLOT >= 0 ? (SLOT + 3) & (NS - 1) : (t + 3) & (NS - 1));
+        if (STEADY || t + 3 < nt) issue_tile(t + 3, SLOT >= 0 ? (SLOT + 3) & (NS - 1) : (t + 3) & (NS - 1));
 #endif
         PHT(h3);
 #ifdef COGS_PHASE_STAMPS
@@ -755,15 +775,25 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     };
 
     PSTAMP();      // 2: S(0) ready
+#ifndef AV_OLD_BRANCHES
+    // A wave whose 32 query rows all lie past the segment end (the ragged last query block) only stages and keeps the barriers: it
+    // walks the tile heads here and leaves, so the waves that compute carry no `wave_active` test between a tile's barrier and its MFMAs
+    if (!wave_active) {
+        for (int ti = 0; ti < nt; ++ti) tile_head(ti, std::integral_constant<int, -1>{}, std::false_type{});
+        return;
+    }
+#endif
     int t = 0;
     using Full = std::integral_constant<int, 1>;
 #ifndef AV_NO_UNROLL4
     // four tiles per trip: t is a multiple of 4 here, so tile t + i sits in ring slot i (compile-time LDS addresses)
-    for (; 2 * (t + 3) + 2 < nfull; t += 4) {
+    for (; 2 * (t + 3) + 2 < nfull && t + 6 < nt; t += 4) {      // (t + 6 < nt: the tile the trip's last head requests exists)
 #ifdef ABL_NOCOMPUTE
 #define COGS_AV_ACTIVE false
-#else
+#elif defined(AV_OLD_BRANCHES)
 #define COGS_AV_ACTIVE wave_active
+#else
+#define COGS_AV_ACTIVE true
 #endif
 #ifdef COGS_PHASE_STAMPS
 #define COGS_PH_ADD(a_, b_, c_) ph_acc[4] += (b_) - (a_); ph_acc[5] += (c_) - (b_);
@@ -771,7 +801,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #define COGS_PH_ADD(a_, b_, c_)
 #endif
 #define COGS_AV_TILE(I)                                                                                      \
-        tile_head(t + I, std::integral_constant<int, I>{});                                                  \
+        tile_head(t + I, std::integral_constant<int, I>{}, std::true_type{});                                                  \
         if (COGS_AV_ACTIVE) {                                                                                \
             unsigned long long c0_ = 0, c1_ = 0, c2_ = 0;                                                    \
             PHT(c0_);                                                                                        \
@@ -786,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     }
 #endif
     for (; 2 * t + 2 < nfull; ++t) {              // blocks 2t+1 and 2t+2 are full
-        tile_head(t, std::integral_constant<int, -1>{});
+        tile_head(t, std::integral_constant<int, -1>{}, std::false_type{});
 #ifndef ABL_NOCOMPUTE
         if (wave_active) {
             substep(sa, sb, 2 * t, Full{}, std::integral_constant<int, -1>{});
@@ -805,7 +835,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     for (; t < nt; ++t) {                         // the ragged end: block kinds decided at run time (wave-uniform)
         unsigned long long q0_ = 0, q1_ = 0;
         PHT(q0_);
-        tile_head(t, std::integral_constant<int, -1>{});
+        tile_head(t, std::integral_constant<int, -1>{}, std::false_type{});
         PHT(q1_);
 #ifdef COGS_PHASE_STAMPS
         tl_acc[0] += q1_ - q0_;
