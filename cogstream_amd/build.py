@@ -35,12 +35,14 @@ def _stale(target: Path, deps) -> bool:
 
 
 OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
-EPI_BIAS, EPI_RES, EPI_ROPE, EPI_ROPE_LUT, EPI_ROWSTAT, EPI_LNFOLD = 1, 2, 4, 512, 1024, 2048      # csrc/gemm_epilogue.h
+EPI_BIAS, EPI_RES, EPI_ROPE, EPI_SWIGLU, EPI_ROPE_LUT, EPI_ROWSTAT, EPI_LNFOLD = 1, 2, 4, 32, 512, 1024, 2048      # csrc/gemm_epilogue.h
 _VMEM = re.compile(r"^\s*(global_load|global_store|buffer_load|buffer_store|flat_load|flat_store|scratch_)")
 
 
 def epi_pair_vmem_ops(epi: int) -> int:
     """csrc/gemm_epilogue.h::epi_pair_vmem_ops<EPI>()"""
+    if epi & EPI_SWIGLU:
+        return 8
     return 16 + (4 if epi & EPI_BIAS else 0) + (16 if epi & EPI_RES else 0) + \
         ((8 if epi & EPI_ROPE_LUT else 32) if epi & EPI_ROPE else 0) + (8 if epi & EPI_LNFOLD else 0) + \
         (8 if epi & EPI_ROWSTAT else 0)

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmArgs p) {
     // (A 256x128 ping-pong variant for N = 1152 was measured 10-15 % slower than the ring kernel: 64x64 per
     // wave makes the L segment -- 8 reads + 3 DMA pieces -- too heavy for 16 MFMAs.)
     int epi_ops = 0;   // vector-memory instructions of the previous tile's epilogue when known exactly, else 0
-    constexpr int PAIR_OK = (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0;
+    constexpr int PAIR_OK = (EPI & (EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0 && ((EPI & EPI_SWIGLU) == 0 || EPI == EPI_SWIGLU);
     constexpr int OPS_A = epi_pair_vmem_ops<EPI>();                                   // rotary / plain tile
     constexpr int OPS_B = epi_pair_vmem_ops<(EPI & ~(EPI_ROPE | EPI_ROPE_LUT))>();    // tile right of rope_cols
     auto wait_next_ktile = [&](int ahead, int kt) {
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
     if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
     int epi_ops = 0;       // vector-memory instructions of the previous tile's epilogue when known exactly, else 0
-    constexpr int PAIR_OK = (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0;
+    constexpr int PAIR_OK = (EPI & (EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0 && ((EPI & EPI_SWIGLU) == 0 || EPI == EPI_SWIGLU);
     constexpr int OPS_A = epi_pair_vmem_ops<EPI>();                                   // rotary / plain tile
     constexpr int OPS_B = epi_pair_vmem_ops<(EPI & ~(EPI_ROPE | EPI_ROPE_LUT))>();    // tile right of rope_cols
     // Slab g+1 = A(g+1), W(g+1) has landed when at most the 4 pieces of A(g+2) -- the only unit a wave issues after

@@ -721,9 +721,42 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
     asm volatile("s_nop 10" ::: "memory");
 }
 
+// SwiGLU (Qwen2 gate / up, weight rows interleaved: a lane's 4 columns are (gate_i, up_i, gate_i+1, up_i+1)) on the ping-pong
+// kernel's wave region, round 6. The generic path stored its two outputs per lane and n-tile as two 2-byte stores (64
+// global_store_short per wave and tile, each with its own 64-bit address and exec mask). Here a lane packs its two outputs of an
+// n-tile into one dword, the four lanes that share a row TRANSPOSE their four dwords (n-tile x lane: two v_permlane16_swap, two
+// v_permlane32_swap), and lane group t ends up with the 8 consecutive output columns of n-tile t: ONE 16-byte store per lane and
+// 16-row block, 64 contiguous bytes per row, 8 store instructions per wave and tile -- and an exact count for the relaxed vmcnt
+// of the next tile's first slab. Same arithmetic per element (silu_f(gate) * up, one rounding), so the bits do not change.
+__device__ __forceinline__ void epilogue_pair_swiglu(const EpiArgs& p, int mb, int nb, int lane, f32x4 (&acc0)[4][4],
+                                                     f32x4 (&acc1)[4][4]) {
+    asm volatile("s_nop 8" ::: "memory");      // region markers of the build-time vmem-count check (see epilogue_pair_fast)
+    const int r = lane & 15, g4 = lane >> 4;
+    char* cbase = p.C + ((long)mb * p.ldc + (nb >> 1)) * 2;
+    const unsigned c_lane = ((unsigned)r * (unsigned)p.ldc + (unsigned)(8 * g4)) * 2u;
+    const long c_row16 = p.ldc * 32;
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+        unsigned d[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 v = blk < 4 ? acc0[blk][ni] : acc1[blk - 4][ni];
+            d[ni] = pack_bf2(silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
+        }
+        // 4 x 4 transpose over the lane rows {r, r+16, r+32, r+48}: row t collects n-tile t's dwords of rows 0..3 in order
+        const auto e = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);     // e[0] = [d0@0 d1@0 d0@2 d1@2], e[1] = [d0@1 d1@1 d0@3 d1@3]
+        const auto f = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
+        const auto x = __builtin_amdgcn_permlane32_swap((unsigned)e[0], (unsigned)f[0], false, false);   // x[0] = [d0@0 d1@0 d2@0 d3@0], x[1] = [..@2]
+        const auto y = __builtin_amdgcn_permlane32_swap((unsigned)e[1], (unsigned)f[1], false, false);   // y[0] = [..@1], y[1] = [..@3]
+        *reinterpret_cast<u32x4*>(cbase + blk * c_row16 + c_lane) = u32x4{(unsigned)x[0], (unsigned)y[0], (unsigned)x[1], (unsigned)y[1]};
+    }
+    asm volatile("s_nop 10" ::: "memory");
+}
+
 // vector-memory instructions (loads + stores; they share the in-order vmcnt queue) one epilogue_pair_fast<EPI> issues
 template <int EPI>
 constexpr int epi_pair_vmem_ops() {
+    if ((EPI & EPI_SWIGLU) != 0) return 8;      // epilogue_pair_swiglu: one 16-byte store per 16-row block, no loads
     return 16 + ((EPI & EPI_BIAS) ? 4 : 0) + ((EPI & EPI_RES) ? 16 : 0) +
            ((EPI & EPI_ROPE) ? ((EPI & EPI_ROPE_LUT) ? 8 : 32) : 0) + ((EPI & EPI_LNFOLD) ? 8 : 0) +
            ((EPI & EPI_ROWSTAT) ? 8 : 0);
@@ -734,6 +767,13 @@ template <typename T, int EPI>
 __device__ __forceinline__ int epilogue_wave_pair(const EpiArgs& p, int mb, int nb, int M, int N, int lane,
                                                   f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4]) {
 #ifndef COGS_EPI_NOPAIR   // (A/B builds; also the build's fallback when the vmem-count check fails)
+    if constexpr (sizeof(T) == 2 && EPI == EPI_SWIGLU) {
+        // N / 2 output columns: the wave's 64 input columns are 32 outputs = 64 bytes per row
+        if (mb + 128 <= M && nb + 64 <= N && (p.ldc & 7) == 0 && (reinterpret_cast<unsigned long>(p.C) & 15) == 0) {
+            epilogue_pair_swiglu(p, mb, nb, lane, acc0, acc1);
+            return epi_pair_vmem_ops<EPI>();
+        }
+    }
     if constexpr (sizeof(T) == 2 && (EPI & (EPI_SWIGLU | EPI_F32OUT | EPI_GENERIC | EPI_NOSTORE)) == 0) {
         bool fast = mb + 128 <= M && nb + 64 <= N && (N & 31) == 0 && (reinterpret_cast<unsigned long>(p.C) & 15) == 0;
         if constexpr ((EPI & EPI_HM) != 0) fast = fast && (p.hm_cols & 63) == 0 && (p.hm_hd & 7) == 0;

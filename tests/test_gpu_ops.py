@@ -549,6 +549,9 @@ def test_pair_epilogue_and_relaxed_vmcnt_equal_the_generic_build_bit_for_bit(dev
         ("fc2+res", dict(a=big, w=rnd(H, I), bias=rnd(H), residual=rnd(M, H))),
         ("plain", dict(a=x, w=rnd(3584, H))),
         ("proj gelu-erf", dict(a=x, w=rnd(3584, H), bias=rnd(3584), act=L2.ACT_GELU_ERF)),
+        # round 6: the SwiGLU pair epilogue (lane transpose, 16-byte stores) against the generic one's two 2-byte stores
+        ("gate/up swiglu", dict(a=x, w=rnd(2 * 2048, H), act=L2.ACT_SWIGLU)),
+        ("gate/up swiglu, ragged N", dict(a=x, w=rnd(2 * 2000, H), act=L2.ACT_SWIGLU)),
     ]
     for name, kw in cases:
         for rep in range(2):

@@ -9,6 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cogstream_amd import _lib as L  # noqa: E402
 from cogstream_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -27,16 +28,20 @@ for name, M, N, K in shapes:
     w = ((torch.rand(N, K, device=dev) * 2 - 1) * 0.05).bfloat16()
     bias = torch.rand(N, device=dev).bfloat16()
     res = torch.rand(M, N, device=dev).bfloat16() if (os.environ.get("AB_RESIDUAL") == "1" and N <= 4608) else None
+    swiglu = os.environ.get("AB_SWIGLU") == "1" and "gate" in name        # the fused SwiGLU epilogue of the Qwen2 MLP (no bias)
     outs, ts = {}, {n: [] for n in ["default"] + names}
     random.seed(M + N)
     for r in range(ROUNDS):
         order = [("default", None)] + alts
         random.shuffle(order)                 # no variant always runs first in a round
         for tag, lib in order:
-            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            out = torch.empty(M, N // 2 if swiglu else N, device=dev, dtype=torch.bfloat16)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ops.gemm(a, w, bias=bias, residual=res, out=out, lib=lib)
+            if swiglu:
+                ops.gemm(a, w, act=L.ACT_SWIGLU, out=out, lib=lib)
+            else:
+                ops.gemm(a, w, bias=bias, residual=res, out=out, lib=lib)
             e1.record()
             torch.cuda.synchronize()
             if r:
