@@ -803,6 +803,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
             m0 += rg * 128;
             n0 += cg * 64;
         }
+#ifdef COGS_GEMM_TSTAMPS     // diagnostic build (tools/gemm_trace.py): K loop / tile boundary of workgroup 0, waves 0 and 4, per tile
+        const bool ts_on = p.trace && blockIdx.x == 0 && wc == 0;
+        const int ts_i = (t - (int)blockIdx.x) / (int)gridDim.x;
+        if (ts_on && ts_i < 24) { const unsigned long long tm_ = __builtin_amdgcn_s_memtime(); if (lane == 0) p.trace[grp * 96 + 4 * ts_i] = tm_; }
+#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -924,11 +929,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp64_kernel(GemmArgs p) {
         // MFMA segment + epilogue) instead of taking one each while the other group waits at a barrier.
         // W of the next tile's second slab goes out in front of the epilogue, into the position of this tile's last A
         // unit: a wave stages rows 32w..32w+31 of it, rows that only its own group read (before this point).
+#ifdef COGS_GEMM_TSTAMPS
+        if (ts_on && ts_i < 24) { const unsigned long long tm_ = __builtin_amdgcn_s_memtime(); if (lane == 0) { p.trace[grp * 96 + 4 * ts_i + 1] = tm_; p.trace[grp * 96 + 4 * ts_i + 2] = tm_; } }
+#endif
         if (grp == 0 || p.epi_serial) __builtin_amdgcn_s_barrier();
         issue_w();
         pre_issued = true;
         int ops = -2;      // -2: this wave had no region (tall tile) and issued nothing
         if (!idle) ops = epilogue_wave_pair<T, EPI>(p.epi, m0, n0, p.M, p.N, lane, acc[0], acc[1]);
+#ifdef COGS_GEMM_TSTAMPS
+        if (ts_on && ts_i < 24) { const unsigned long long tm_ = __builtin_amdgcn_s_memtime(); if (lane == 0) p.trace[grp * 96 + 4 * ts_i + 3] = tm_; }
+#endif
         if (grp == 1 && !p.epi_serial) __builtin_amdgcn_s_barrier();
 #ifdef COGS_EPI_CONSERVATIVE
         epi_ops = ops == -2 ? -2 : 0;
@@ -1020,8 +1031,8 @@ void launch_pp(hipStream_t st, const GemmArgs& p, int grid) {
         for (int g = 0; g < 2; ++g) {
             fprintf(stderr, "[gemm trace] EPI=%d M=%d N=%d K=%d group %d:", EPI, p.M, p.N, p.K, g);
             for (int i = 0; i + 3 < 96 && h[g * 96 + i + 3]; i += 4)
-                fprintf(stderr, " k%llu/e%llu+%llu", h[g * 96 + i + 1] - h[g * 96 + i], h[g * 96 + i + 2] - h[g * 96 + i + 1],
-                        h[g * 96 + i + 3] - h[g * 96 + i + 2]);
+                fprintf(stderr, " k%llu/e%llu+%llu(+%llu to the next tile's top)", h[g * 96 + i + 1] - h[g * 96 + i], h[g * 96 + i + 2] - h[g * 96 + i + 1],
+                        h[g * 96 + i + 3] - h[g * 96 + i + 2], (i + 4 < 96 && h[g * 96 + i + 4]) ? h[g * 96 + i + 4] - h[g * 96 + i + 3] : 0ull);
             fprintf(stderr, "\n");
         }
 #ifdef COGS_GEMM_KSTAMPS

@@ -608,7 +608,7 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
         for (int j = 0; j < UPB; ++j) {
             const int u = UPB * b + j, blk = u >> 1, pr = u & 1;
             if constexpr ((EPI & EPI_LNFOLD) != 0) {
-                if (pr == 0) rs_ring[UPB == 1 ? (blk & 1) : blk] = *reinterpret_cast<const float*>(rsbase + blk * 128);
+                if (pr == 0) rs_ring[UPB == 1 ? (blk & 7) : blk] = *reinterpret_cast<const float*>(rsbase + blk * 128);
             }
             if constexpr ((EPI & EPI_RES) != 0)
                 res_wide[b][j] = *reinterpret_cast<const u32x4*>(rbase + blk * r_row16 + r_lane + 64 * pr);
@@ -639,7 +639,7 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
                 const int ni = 2 * pr + h2;
                 v[h2] = (blk < 4) ? acc0[mi][ni] : acc1[mi][ni];
                 if constexpr ((EPI & EPI_LNFOLD) != 0) {
-                    const float rs = rs_ring[UPB == 1 ? (blk & 1) : blk];
+                    const float rs = rs_ring[UPB == 1 ? (blk & 7) : blk];
 #ifdef COGS_EPI_SCALAR_MATH
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[h2][e] = fmaf(rs, v[h2][e], bias_v[ni][e]);
@@ -711,11 +711,20 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
         }
     };
     constexpr bool HAS_LOADS = (EPI & (EPI_RES | EPI_ROPE | EPI_LNFOLD)) != 0;
-    if constexpr (HAS_LOADS) { load_batch(0); load_batch(1); }
+    // batches in flight: 2, or -- rotary (1-unit batches of two 16-byte table loads: round 6's tile stamps put a rotary tile's
+    // epilogue at 15.5 k cycles against 5 k for a plain one, sixteen load round trips two at a time) -- COGS_ROPE_DEPTH
+#ifndef COGS_ROPE_DEPTH
+#define COGS_ROPE_DEPTH 4
+#endif
+    constexpr int DEPTH = (EPI & EPI_ROPE) != 0 ? COGS_ROPE_DEPTH : 2;
+    if constexpr (HAS_LOADS) {
+#pragma unroll
+        for (int b = 0; b < DEPTH; ++b) load_batch(b);
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         math_batch(b);
-        if constexpr (HAS_LOADS) { if (b + 2 < NB) load_batch(b + 2); }   // before this batch's stores (see above)
+        if constexpr (HAS_LOADS) { if (b + DEPTH < NB) load_batch(b + DEPTH); }   // before this batch's stores (see above)
         store_batch(b);
     }
     asm volatile("s_nop 10" ::: "memory");

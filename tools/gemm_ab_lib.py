@@ -29,6 +29,8 @@ for name, M, N, K in shapes:
     bias = torch.rand(N, device=dev).bfloat16()
     res = torch.rand(M, N, device=dev).bfloat16() if (os.environ.get("AB_RESIDUAL") == "1" and N <= 4608) else None
     swiglu = os.environ.get("AB_SWIGLU") == "1" and "gate" in name        # the fused SwiGLU epilogue of the Qwen2 MLP (no bias)
+    rope = os.environ.get("AB_ROPE") == "1" and name == "ViT qkv"         # bias + rotary (interleaved (cos, sin) table) on q | k
+    table = torch.rand(M, 36, 2, device=dev) if rope else None
     outs, ts = {}, {n: [] for n in ["default"] + names}
     random.seed(M + N)
     for r in range(ROUNDS):
@@ -40,6 +42,8 @@ for name, M, N, K in shapes:
             e0.record()
             if swiglu:
                 ops.gemm(a, w, act=L.ACT_SWIGLU, out=out, lib=lib)
+            elif rope:
+                ops.gemm(a, w, bias=bias, rope_cos=table, rope_cols=2304, head_dim=72, out=out, lib=lib)
             else:
                 ops.gemm(a, w, bias=bias, residual=res, out=out, lib=lib)
             e1.record()
