@@ -691,12 +691,41 @@ __device__ __forceinline__ void epilogue_pair_fast(const EpiArgs& p, int mb, int
             outv[j] = u32x4{s0[0], s1[0], s0[1], s1[1]};
         }
     };
+    // WHOLE-LINE stores (round 6; row-major output, 4-unit batches). A unit's store is 16 rows x 64 bytes: sixteen HALF lines per
+    // instruction, which the CU's vector-memory path takes at ~30 B/clk against ~54 for whole lines -- and a plain tile's 128 store
+    // instructions are its whole 5 k-cycle epilogue (profiles/r6_gemm_tile_stamps.txt). The two units of a 16-row block hold, per
+    // lane (row r, column group), the first and the second 64 bytes of row r; lanes r and r ^ 8 swap one of them (8 v_mov_dpp
+    // row_ror:8 with a bank mask per row block), after which lane r < 8 holds the first halves of rows r and r + 8 and lane r >= 8
+    // the second halves of rows r - 8 and r: store A writes rows 0..7 of the block as whole 128-byte lines, store B rows 8..15.
+    // Same bytes, same number of store instructions (the relaxed vmcnt counts stay).
+    constexpr bool WHOLE_LINES = (EPI & EPI_HM) == 0 && UPB == 4;
+    unsigned c_laneA = 0;
+    if constexpr (WHOLE_LINES) c_laneA = ((unsigned)(r & 7) * (unsigned)p.ldc + (unsigned)wcol) * 2u + (unsigned)(r >> 3) * 64u;
+    auto ror8_hi = [](unsigned keep, unsigned give) -> unsigned {      // lanes 8..15 of every row of 16: `give` of lane - 8; lanes 0..7: keep
+        return (unsigned)__builtin_amdgcn_update_dpp((int)keep, (int)give, 0x128, 0xf, 0xc, false);
+    };
+    auto ror8_lo = [](unsigned keep, unsigned give) -> unsigned {      // lanes 0..7: `give` of lane + 8; lanes 8..15: keep
+        return (unsigned)__builtin_amdgcn_update_dpp((int)keep, (int)give, 0x128, 0xf, 0x3, false);
+    };
     auto store_batch = [&](const int b) {
+        if constexpr (WHOLE_LINES) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {                    // the batch's two row blocks
+                const int blk = 2 * b + k;
+                const u32x4 o0 = outv[2 * k], o1 = outv[2 * k + 1];
+                u32x4 da, db;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { da[e] = ror8_hi(o0[e], o1[e]); db[e] = ror8_lo(o1[e], o0[e]); }
+                *reinterpret_cast<u32x4*>(cbase + blk * c_row16 + c_laneA) = da;
+                *reinterpret_cast<u32x4*>(cbase + blk * c_row16 + (c_row16 >> 1) + c_laneA) = db;
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < UPB; ++j) {
             const int u = UPB * b + j, blk = u >> 1, pr = u & 1;
             if constexpr ((EPI & EPI_HM) != 0) *reinterpret_cast<u32x4*>(cbase + blk * c_row16 + (pr ? c_lane1 : c_lane)) = outv[j];
             else *reinterpret_cast<u32x4*>(cbase + blk * c_row16 + c_lane + 64 * pr) = outv[j];
+        }
         }
         if constexpr ((EPI & EPI_ROWSTAT) != 0) {
             static_assert((EPI & EPI_ROWSTAT) == 0 || UPB == 4, "row statistics are laid out for 4-unit batches");
