@@ -31,6 +31,7 @@ for name, M, N, K in shapes:
     swiglu = os.environ.get("AB_SWIGLU") == "1" and "gate" in name        # the fused SwiGLU epilogue of the Qwen2 MLP (no bias)
     rope = os.environ.get("AB_ROPE") == "1" and name == "ViT qkv"         # bias + rotary (interleaved (cos, sin) table) on q | k
     table = torch.rand(M, 36, 2, device=dev) if rope else None
+    hm = 1152 if (rope and os.environ.get("AB_HM") == "1") else 0          # head-major q | k | v output as the encoder runs it
     outs, ts = {}, {n: [] for n in ["default"] + names}
     random.seed(M + N)
     for r in range(ROUNDS):
@@ -43,7 +44,7 @@ for name, M, N, K in shapes:
             if swiglu:
                 ops.gemm(a, w, act=L.ACT_SWIGLU, out=out, lib=lib)
             elif rope:
-                ops.gemm(a, w, bias=bias, rope_cos=table, rope_cols=2304, head_dim=72, out=out, lib=lib)
+                out = ops.gemm(a, w, bias=bias, rope_cos=table, rope_cols=2304, head_dim=72, hm_cols=hm, out=(None if hm else out), lib=lib)
             else:
                 ops.gemm(a, w, bias=bias, residual=res, out=out, lib=lib)
             e1.record()
