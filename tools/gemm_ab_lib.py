@@ -19,6 +19,9 @@ alts = [(n, C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 shapes = [("ViT qkv", 59136, 3456, 1152), ("ViT o", 59136, 1152, 1152), ("ViT fc1", 59136, 4352, 1152), ("ViT fc2", 59136, 1152, 4352),
           ("Qwen2 qkv", 15396, 4608, 3584), ("Qwen2 o", 15396, 3584, 3584), ("Qwen2 gate/up", 15396, 37888, 3584),
           ("Qwen2 down", 15396, 3584, 18944)]
+for item in filter(None, os.environ.get("AB_EXTRA", "").split(",")):      # AB_EXTRA="ring fc2:3696:1152:4352,..." adds shapes
+    nm, m_, n_, k_ = item.split(":")
+    shapes.append((nm, int(m_), int(n_), int(k_)))
 ROUNDS = int(os.environ.get("AB_ROUNDS", "7"))     # AB_ROUNDS=25 resolves ~0.5 %
 only = os.environ.get("AB_ONLY")                    # comma-separated substrings of shape names
 for name, M, N, K in shapes:
