@@ -108,7 +108,7 @@ def _disassemble(obj: Path, tag: str) -> str:
             f.unlink()
 
 
-def check_m0_uses(obj: Path, kernel: str = "attn_vit_pipe_kernel"):
+def check_m0_uses(obj: Path, kernel=("attn_vit_pipe_kernel", "attn_vit_tail_kernel")):
     """csrc/attn_vit.hip issues its LDS-DMA pieces from inline asm that writes M0 (`s_mov_b32 m0, sN` right in front of
     `global_load_lds_dwordx4`) without naming M0 as clobbered (hipcc warns about the clobber and never keeps a value in
     M0 across statements). That assumption is checked here instead: inside attn_vit_pipe_kernel every instruction that
@@ -118,7 +118,7 @@ def check_m0_uses(obj: Path, kernel: str = "attn_vit_pipe_kernel"):
     for line in _disassemble(obj, "m0_check").splitlines():
         m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
         if m:
-            inside = kernel in m.group(1)
+            inside = any(k in m.group(1) for k in ((kernel,) if isinstance(kernel, str) else kernel))
             continue
         ins = line.split("//")[0].strip()
         if inside and re.search(r"\bm0\b", ins) and not re.match(r"^s_mov_b32 m0, s\d+$", ins):
