@@ -108,7 +108,7 @@ def _disassemble(obj: Path, tag: str) -> str:
             f.unlink()
 
 
-def check_m0_uses(obj: Path, kernel=("attn_vit_pipe_kernel", "attn_vit_tail_kernel")):
+def check_m0_uses(obj: Path, kernel="attn_vit_pipe_kernel"):
     """csrc/attn_vit.hip issues its LDS-DMA pieces from inline asm that writes M0 (`s_mov_b32 m0, sN` right in front of
     `global_load_lds_dwordx4`) without naming M0 as clobbered (hipcc warns about the clobber and never keeps a value in
     M0 across statements). That assumption is checked here instead: inside attn_vit_pipe_kernel every instruction that

@@ -41,7 +41,6 @@ struct VitAttnArgs {
     long head_stride;          // elements from head h to head h + 1 of Q / K / V: HD for the token-major layout (ld* = row stride of
                                // the fused qkv buffer), rows * HD for the head-major one (ld* = HD: a head's rows back to back, so a
                                // key tile is ONE contiguous run of 64 x 144 bytes and every 1 KiB LDS-DMA piece is whole lines)
-    int split_tail;            // 1: the pipelined kernel runs a last query block of <= 32 rows split over the keys (attn_vit_tail_block)
     int uniform_len;           // > 0: every segment has this many rows and segment s starts at row s * uniform_len (one video:
                                // all frames alike) -- the bounds are then arithmetic on kernel arguments instead of two
                                // dependent scalar loads at the head of every workgroup (700-1 700 cycles of its 39 000)
@@ -52,6 +51,14 @@ constexpr float RESCALE_THR = 6.0f;
 #if defined(COGS_ATTN_STAMPS) || defined(COGS_PIPE_STAMPS) || defined(COGS_PHASE_STAMPS)   // diagnostic builds (tools/micro/attn_vit_micro.cpp)
 __device__ unsigned long long g_attn_stamps[8];
 __device__ unsigned long long g_tail_stamps[8];
+#endif
+#ifdef COGS_LIFE_STAMPS   // tools/micro/attn_vit_micro.cpp: summed workgroup lifetimes (s_memtime), wave 0
+__device__ unsigned long long g_av_life[8];
+#define LIFE_NOW(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LIFE_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_av_life[i], (unsigned long long)(v)); } while (0)
+#else
+#define LIFE_NOW(v) do {} while (0)
+#define LIFE_ADD(i, v) do {} while (0)
 #endif
 #ifdef COGS_ATTN_STAMPS   // where does a tile's time go, wave 0 of one workgroup
 #define STAMP(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - st_prev; st_prev = now_; } while (0)
@@ -363,268 +370,6 @@ __global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Round 6: the ragged last query block, split over the KEYS.
-// 924 patches are 7 query blocks of 128 rows and one of 28: in the kernels above that eighth workgroup computes on ONE wave
-// (three only stage) yet holds its half CU for a whole workgroup time -- 3/32 of the launch's wave slots idle, the largest
-// single loss the stamps showed. Here a query block of <= 32 rows goes to a workgroup whose four waves all own
-// the SAME rows and every fourth key tile each (tile t -> wave t % 4): 4 instead of 15 tiles deep, no workgroup barrier
-// inside the tile walk, one merge through LDS at the end. Called by the pipelined kernel for such a block (p.split_tail), in
-// the SAME launch: as a launch of its own behind the main kernel it re-read every K and V from HBM (272 MB per layer at cfg2, the
-// other query blocks of its (frame, head) long gone from the L2) and the attention got 8 % SLOWER (profiles/r6_attn_vit_tail.txt).
-//   * a wave is a complete little attention of its own: K fragments come straight from global memory into the A-operand
-//     registers (lane (key, k-half) reads 16 bytes of its key's row: nothing to transpose), V goes global -> LDS by DMA into
-//     the wave's PRIVATE double buffer (plain 64 x 144-byte image, read by ds_read_b64_tr_b16 exactly as in the pipelined
-//     kernel), both one tile ahead; a wave waits on its own vmcnt only;
-//   * same products, pad-column bookkeeping and deferred maximum as above; the partial results (O^T relative to the wave's
-//     reference, the reference, the denominator row) meet in LDS and are combined as sum_w 2^(m_w - m) O_w, m = max m_w.
-// LDS: 4 waves x 2 x 9 216 B + the two constant chunks, inside the pipelined kernel's request (two workgroups per CU).
-template <int HD>
-__device__ __forceinline__ void attn_vit_tail_block(const VitAttnArgs& p, char* const smem, const int head, const int qs, const int qe, const int q0) {
-    constexpr int NW = 4;
-    static_assert(HD % 8 == 0 && HD % 16 == 8 && HD < 96, "pad column HD must open a fresh 16-byte chunk inside the last k-step");
-    constexpr int KS = (HD + 8) / 16, DB = (HD + 8 + 31) / 32, CH = HD / 8;
-    constexpr int RS = HD * 2, TILE = 64 * RS, PIECES = TILE / 1024;
-    static_assert(TILE % 1024 == 0, "a tile is a whole number of 1 KiB pieces");
-    constexpr int WAVE_LDS = 2 * TILE;                           // a wave's two V images; later its merge record
-    constexpr int C_ONE = NW * WAVE_LDS, C_ZERO = C_ONE + 16;
-    constexpr int NACC = DB * 16;                                // accumulator registers per lane
-    static_assert((NACC + 1) * 256 <= WAVE_LDS, "merge record fits the wave's buffers");
-    static_assert(NW * WAVE_LDS + 64 <= 4 * (2 * TILE + 64), "fits the pipelined kernel's LDS request");
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, r32 = lane & 31;
-    const int len = qe - qs;
-    const int nt = (len + 63) >> 6;
-
-    if (tid == 0) {
-        *reinterpret_cast<u32x4*>(smem + C_ONE) = u32x4{0x00003f80u, 0, 0, 0};
-        *reinterpret_cast<u32x4*>(smem + C_ZERO) = u32x4{0, 0, 0, 0};
-    }
-    const int qrow = q0 + r32;
-    const bool qok = qrow < qe;
-    u32x4 qf[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int k = 16 * s + 8 * h;
-        qf[s] = u32x4{0, 0, 0, 0};
-        if (qok && k < HD) qf[s] = *reinterpret_cast<const u32x4*>(p.Q + (long)qrow * p.ldq + head * p.head_stride + k);
-    }
-
-    const bf16_t* kbase = p.K + (long)qs * p.ldk + head * p.head_stride;
-    const bf16_t* vbase = p.V + (long)qs * p.ldv + head * p.head_stride;
-    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    char* const my_lds = smem + wid * WAVE_LDS;
-    auto uniform_ptr = [](const bf16_t* q) -> const bf16_t* {
-        const unsigned long long v = (unsigned long long)q;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return (const bf16_t*)(((unsigned long long)hi << 32) | lo);
-    };
-    auto dma16 = [&](const bf16_t* base, int off_bytes, unsigned lds) {      // see attn_vit_pipe_kernel (M0, hidden from hipcc)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :: "s"(lds), "v"(off_bytes), "s"(base) : "memory");
-    };
-    // K fragments of tile t: lane (key r32 of block kb, k-half h) <- 16 bytes at column 16 ks + 8 h of its key's row; keys past
-    // the end read the last row (finite; their scores are masked). k-step KS-1: half 0 = columns 64..71, half 1 = the pad chunk
-    // [1, 0 x7] -- every lane loads half 0's address (in range for all) and half 1 drops it
-    auto load_k = [&](int t, u32x4 (&kr)[2][KS]) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int row = min(t * 64 + 32 * kb + r32, len - 1);
-            const bf16_t* kp = kbase + (long)row * p.ldk;
-#pragma unroll
-            for (int ks = 0; ks < KS - 1; ++ks) kr[kb][ks] = *reinterpret_cast<const u32x4*>(kp + 16 * ks + 8 * h);
-            kr[kb][KS - 1] = *reinterpret_cast<const u32x4*>(kp + 16 * (KS - 1));
-        }
-    };
-    // V image of tile t -> this wave's buffer `slot`: 9 pieces of 1 KiB, chunk c = 64 j + lane = (row c / 9, 16-byte column c % 9)
-    auto issue_v = [&](int t, int slot) {
-        const int valid = len - t * 64;                          // >= 1
-        const bf16_t* vb = uniform_ptr(vbase + (long)t * 64 * p.ldv);
-        const unsigned st = __builtin_amdgcn_readfirstlane(smem_lds + wid * WAVE_LDS + slot * TILE);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));      // the piece offsets are computed HERE, every tile (hoisted out of the loop they cost 27 spilled registers)
-#pragma unroll
-        for (int j = 0; j < PIECES; ++j) {
-            const int c = 64 * j + ln;
-            const int row = min(c / CH, valid - 1);
-            dma16(vb, (row * (int)p.ldv + (c % CH) * 8) * 2, st + j * 1024);
-        }
-    };
-    const int v_d = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    const int v_rd = (4 * h + ((lane & 15) >> 2)) * RS + v_d * 2;
-    constexpr int DL = 32 * (DB - 1);
-    const bool v_last_real = DL + v_d < HD;
-    const int v_last_const = DL + v_d == HD ? C_ONE : C_ZERO;
-    auto read_v = [&](const char* img, int b, int kb, int s2) -> u32x4 {
-        const int koff = (32 * kb + 16 * s2) * RS;
-        const char* a0 = img + v_rd + koff + b * 64;
-        const char* a1 = a0 + 8 * RS;
-        if (b == DB - 1) {
-            a0 = v_last_real ? a0 : smem + v_last_const;
-            a1 = v_last_real ? a1 : smem + v_last_const;
-        }
-        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(a0));
-        const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(a1));
-        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-        return u32x4{l2[0], l2[1], h2[0], h2[1]};
-    };
-
-    f32x16 oacc[DB];
-#pragma unroll
-    for (int b = 0; b < DB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[b][r] = 0.f;
-    float sh = 0.f;
-    bool first = true;
-
-    // ONE set of K fragment registers: a tile's fragments are dead once its scores stand (after the rare path's decision), and the
-    // next tile's loads go into the same registers right there, under the exponentials and the PV product
-    u32x4 kf[2][KS];
-    int t = wid;
-    if (t < nt) { load_k(t, kf); issue_v(t, 0); }
-    __syncthreads();                                             // the constant chunks (every wave comes by here exactly once)
-
-    // one 32-key block at a time (scores 16, P 8, V fragments 24 registers live: whole tiles in flight made hipcc spill)
-    auto compute = [&](const char* img, const int valid, const int t_next, auto masked_tag) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int vblk = valid - 32 * kb;                    // MASKED: keys >= vblk of this block do not exist
-            if (MASKED && vblk <= 0) {                           // wave-uniform: no second block; the next tile's K loads still go out
-                if (t_next < nt) load_k(t_next, kf);
-                break;
-            }
-            f32x16 sc;
-            auto qk = [&]() {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    f32x16 c0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) c0[r] = 0.f;
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb][s]), __builtin_bit_cast(bf16x8, qf[s]),
-                                                                 s == 0 ? c0 : sc, 0, 0, 0);
-                }
-                if constexpr (MASKED) {
-                    int vh = vblk - 4 * h;                       // key = (r & 3) + 8 (r >> 2) + 4 h >= vblk, as ONE per-lane bound against
-                    asm volatile("" : "+v"(vh));                 // constants (sixteen per-lane key numbers get hoisted and spilled)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if ((r & 3) + 8 * (r >> 2) >= vh) sc[r] = -INFINITY;
-                }
-            };
-            qk();
-            u32x4 vf[DB][2];
-#pragma unroll
-            for (int b = 0; b < DB; ++b)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) vf[b][s2] = read_v(img, b, kb, s2);
-            float d = sc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) d = fmaxf(d, sc[r]);
-            {
-                const unsigned db = __builtin_bit_cast(unsigned, d);
-                const auto sw = __builtin_amdgcn_permlane32_swap(db, db, false, false);
-                d = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
-            }
-            if (first || __any(d > RESCALE_THR)) {               // wave-uniform: move the reference, rescale O, recompute the block's scores
-                float dd = first ? d : fmaxf(d, 0.f);
-                if (!(dd > -INFINITY)) dd = 0.f;
-                const float m_new = (first || d > RESCALE_THR) ? bf16_round(sh + dd) : sh;
-                if (!first) {
-                    const float al = __builtin_amdgcn_exp2f(sh - m_new);
-#pragma unroll
-                    for (int b = 0; b < DB; ++b)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[b][r] *= al;
-                }
-                sh = m_new;
-                const unsigned bits = __float_as_uint(-sh) >> 16;    // exact: sh is a bf16 value
-                if (h) qf[KS - 1][0] = (qf[KS - 1][0] & 0xffff0000u) | bits;
-                first = false;
-                qk();
-            }
-            if (kb == 1 && t_next < nt) load_k(t_next, kf);       // this tile's fragments are dead from here
-            u32x4 pf[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    pf[s2][w] = pack_bf2(__builtin_amdgcn_exp2f(sc[8 * s2 + 2 * w]), __builtin_amdgcn_exp2f(sc[8 * s2 + 2 * w + 1]));
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int b = 0; b < DB; ++b)
-                    oacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[b][s2]), __builtin_bit_cast(bf16x8, pf[s2]),
-                                                                     oacc[b], 0, 0, 0);
-        }
-    };
-
-    // full tiles in one loop, the ragged last tile (one wave has it) behind it: both variants inside one loop body made hipcc
-    // keep two register assignments alive (256 registers + 16 spilled against 177)
-    int slot = 0;
-    auto tile = [&](auto masked_tag) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's K fragments and V image of tile t
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(kf[kb][s]));      // landed: no compiler wait inside the tile
-            if (h) kf[kb][KS - 1] = u32x4{0x00003f80u, 0, 0, 0};
-        }
-        if (t + NW < nt) issue_v(t + NW, slot ^ 1);
-        compute(my_lds + slot * TILE, len - t * 64, t + NW, masked_tag);
-        slot ^= 1;
-    };
-    const int full_tiles = len >> 6;
-    for (; t < full_tiles; t += NW) tile(std::false_type{});
-    if (t < nt) tile(std::true_type{});
-
-    // ---- merge: every wave leaves [register][lane] fp32 records of O^T and its reference in its own (now idle) buffers
-    float* rec = reinterpret_cast<float*>(my_lds);
-#pragma unroll
-    for (int b = 0; b < DB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rec[(b * 16 + r) * 64 + lane] = oacc[b][r];
-    rec[NACC * 64 + lane] = first ? -INFINITY : sh;              // a wave without a tile (fewer tiles than waves) weighs nothing
-    __syncthreads();
-    float mw[NW], m = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        mw[w] = reinterpret_cast<const float*>(smem + w * WAVE_LDS)[NACC * 64 + lane];
-        m = fmaxf(m, mw[w]);
-    }
-    float fw[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) fw[w] = __builtin_amdgcn_exp2f(mw[w] - m);      // wave 0 always has tile 0: m is finite
-    constexpr int LB = HD / 32, LR = HD % 32;
-    constexpr int LH = (LR >> 2) & 1, LREG = (LR & 3) + 4 * (LR >> 3);
-    float l = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) l += fw[w] * reinterpret_cast<const float*>(smem + w * WAVE_LDS)[(LB * 16 + LREG) * 64 + r32 + 32 * LH];
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    bf16_t* orow = p.O + (long)qrow * p.ldo + head * HD;
-    // output groups (d-block b, half gp): 16 consecutive d; wave w takes group w, wave 0 the fifth as well
-    constexpr int NGRP = (HD + 15) / 16;
-    for (int g = wid; g < NGRP; g += NW) {
-        const int b = g >> 1, gp = g & 1;
-        float o[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) a += fw[w] * reinterpret_cast<const float*>(smem + w * WAVE_LDS)[(b * 16 + 8 * gp + i) * 64 + lane];
-            o[i] = a * inv;
-        }
-        const unsigned e0 = pack_bf2(o[0], o[1]), e1 = pack_bf2(o[2], o[3]), o0 = pack_bf2(o[4], o[5]), o1 = pack_bf2(o[6], o[7]);
-        const auto s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
-        const auto s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
-        const int d0 = 32 * b + 16 * gp + 8 * h;
-        if (qok && d0 < HD) *reinterpret_cast<u32x4*>(orow + d0) = u32x4{(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
 // Software-pipelined variant with LDS-DMA staging: the same products, padding trick and deferred maximum, but
 //   (1) a wave's instruction stream always holds independent matrix AND vector work:
 //         iteration t:   P(t) = exp2(S(t))   beside   S(t+1) = K(t+1).Q^T
@@ -690,6 +435,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #define PHT(v) do {} while (0)
 #endif
     PSTAMP();      // 0: kernel entry
+    unsigned long long life0 = 0, life1 = 0;
+    LIFE_NOW(life0);
     int seg, head, qb;
     {
         const int nhf = p.nseg * p.heads, id = blockIdx.x;      // XCD-aware order, see attn_vit_kernel
@@ -710,11 +457,6 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     PSTAMP();      // segment bounds here
 #endif
     if (q0 >= qe) return;
-    if (p.split_tail && qe - q0 <= 32) {          // workgroup-uniform: a short last query block runs split over the keys
-        if (p.split_tail == 2) return;            // TIMING EXPERIMENT ONLY: the block is not computed at all
-        attn_vit_tail_block<HD>(p, smem, head, qs, qe, q0);
-        return;
-    }
     const int nt = (qe - qs + 63) >> 6;
     const int full_tiles = (qe - qs) >> 6;
 
@@ -1154,6 +896,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             if (qok && d0 < HD) *reinterpret_cast<u32x4*>(orow + d0) = u32x4{(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
         }
     }
+    LIFE_NOW(life1);
+    LIFE_ADD(0, life1 - life0); LIFE_ADD(1, 1);
 #ifdef COGS_PIPE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PSTAMP();      // 5: O stored
@@ -1180,7 +924,6 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     const int variant = (int)g_cogs_debug.attn_vit;     // 1: unpipelined (A/B runs)
     const int env_early = (int)g_cogs_debug.attn_vit_early;
     p.early_prefetch = env_early;
-    p.split_tail = (int)g_cogs_debug.attn_vit_tail;
     if (variant == 1 || a.ldk != a.ldv) { g_cogs_debug.attn_last_kernel = 2; hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p); }
     else {
         g_cogs_debug.attn_last_kernel = a.head_stride > 0 ? 8 : 3;

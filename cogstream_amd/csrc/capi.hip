@@ -161,7 +161,7 @@ static bool cogs_debug_value_ok(const char* name, int64_t v) {
     struct Range { const char* name; int64_t lo, hi; };
     static const Range ranges[] = {
         {"gemm_wgs", 0, 256}, {"gemm_pad_pct", 100, 400}, {"gemm_group_m", 0, 64}, {"gemm_co_streams", 0, 8},
-        {"gemm_ring_cost_permille", 1, 4000}, {"gemv_small_n", 0, 1 << 30}, {"attn_vit", 0, 2}, {"attn_vit_tail", 0, 2}, {"attn_prio", 0, 2},
+        {"gemm_ring_cost_permille", 1, 4000}, {"gemv_small_n", 0, 1 << 30}, {"attn_vit", 0, 2}, {"attn_prio", 0, 2},
         {"attn_nq", 0, 2}, {"vit_split_max", 0, INT64_MAX}, {"llm_split_keys", 0, 1 << 24}, {"km_row_groups", 0, 1 << 16},
     };
     for (const Range& r : ranges)

@@ -36,7 +36,6 @@
     /* ---- attention (csrc/attn.hip, attn_vit.hip, attn_decode.hip) ---- */                                                \
     X(attn_vit, 2, "ViT block-diagonal attention: 2 pipelined LDS-DMA kernel, 1 unpipelined, 0 general kernel")            \
     X(attn_vit_early, 0, "1: pipelined ViT kernel issues tiles 1-2 before its first wait (the order before round 4)")       \
-    X(attn_vit_tail, 1, "ViT attention: 1 a last query block of <= 32 rows runs key-split over the 4 waves of its own workgroup (round 6), 0 as one wave of an ordinary workgroup") \
     X(attn_decode, 1, "0: single-token attention through the general split-KV kernel")                                      \
     X(attn_combine32, 1, "split-KV combine: 1 one block per (head, 32-column slice), 8 loads in flight per thread; 0 one block per head") \
     X(attn_prefill_dma, 1, "0: Qwen2 prompt attention through the general register-staged kernel")                          \

@@ -261,58 +261,6 @@ def test_attention_vit_pipeline_edges(dev, heads, lens, data):
         assert (out[a:b] <= v[a:b].amax(0) + 2e-2).all() and (out[a:b] >= v[a:b].amin(0) - 2e-2).all()
 
 
-@pytest.mark.parametrize("heads,lens", [(16, [924] * 4), (3, [140, 260, 1, 924, 156, 129, 33, 32, 160, 161]), (8, [17] * 3),
-                                        (2, [897, 928, 929, 1024, 65 + 128])])
-@pytest.mark.parametrize("layout", ["token", "head"])
-def test_attention_vit_key_split_last_block(dev, heads, lens, layout):
-    """A last query block of <= 32 rows (924 = 7 x 128 + 28) runs in attn_vit_tail_kernel: its own workgroup, the KEYS dealt
-    tile by tile over the four waves, partial results merged through LDS (debug switch attn_vit_tail, default on). Segments
-    with and without such a block mixed in one launch, fewer key tiles than waves (1, 17, 33, 129 rows), a ragged and an
-    exactly full last key tile, both K/V layouts, growing scores (every wave moves its reference on its own). Against the
-    fp32 softmax row by row; and every row OUTSIDE those blocks must be bit-identical to the launch with the switch off
-    (the main kernel's work on them is unchanged), the rows inside them equal within bf16 rounding."""
-    ops = _ops()
-    from cogstream_amd import _lib as L
-    hd, H = 72, heads * 72
-    n = sum(lens)
-    g = torch.Generator().manual_seed(77 * heads + n)
-    qkv = torch.randn(n, 3 * H, generator=g)
-    qkv[:, :H] *= LOG2E / math.sqrt(hd)
-    u = torch.randn(hd, generator=g)
-    u /= u.norm()
-    pos = torch.cat([torch.arange(x, dtype=torch.float32) for x in lens])
-    for hh in range(0, heads, 2):                          # every other head: scores grow along the keys
-        qkv[:, hh * hd:(hh + 1) * hd] += 1.5 * u
-        qkv[:, H + hh * hd:H + (hh + 1) * hd] += u * (pos[:, None] / 16.0)
-    qkv = qkv.bfloat16()
-    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
-    ref = _attn_ref(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], heads, heads, hd, cu=cu.long(), scale=math.log(2.0))
-    if layout == "head":
-        hm = qkv.view(n, 3, heads, hd).permute(1, 2, 0, 3).contiguous().to(dev)        # [which][head][row][hd]
-        def run():
-            return ops.attention(hm[0], hm[1], hm[2], hq=heads, hkv=heads, head_dim=hd, cu_seqlens=cu.to(dev),
-                                 max_seqlen=max(lens), q_prescaled=True, head_major=True).float().cpu()
-    else:
-        gq = qkv.to(dev)
-        def run():
-            return ops.attention(gq[:, :H], gq[:, H:2 * H], gq[:, 2 * H:], hq=heads, hkv=heads, head_dim=hd,
-                                 cu_seqlens=cu.to(dev), max_seqlen=max(lens), q_prescaled=True).float().cpu()
-    out = run()
-    with L.debug_switch("attn_vit_tail", 0):
-        old = run()
-    assert torch.isfinite(out).all()
-    err = (out - ref).abs().view(n, heads, hd).amax(2) / ref.abs().view(n, heads, hd).amax(2).clamp_min(1e-3)
-    assert float(err.max()) < 3e-2, (float(err.max()), int(err.argmax()) // heads)
-    in_tail = torch.zeros(n, dtype=torch.bool)
-    for i, x in enumerate(lens):
-        first = ((x - 1) // 128) * 128
-        if x - first <= 32:
-            in_tail[int(cu[i]) + first:int(cu[i]) + x] = True
-    assert in_tail.any()
-    assert torch.equal(out[~in_tail], old[~in_tail])
-    assert float((out[in_tail] - old[in_tail]).abs().max()) < 3e-2
-
-
 @pytest.mark.parametrize("S,pos0", [(200, 0), (130, 77), (1, 300), (1, 5000)])
 def test_attention_prescaled_q_causal_gqa(dev, S, pos0):
     ops = _ops()

@@ -50,6 +50,13 @@ int main(int argc, char** argv) {
     }
     const double fl = 4.0 * nseg * heads * (double)seg * seg * hd;
     printf("attn_vit %dx%d: mean %.4f ms min %.4f ms  %.1f TFLOP/s (min)\n", nseg, seg, sum / 20, best, fl / best / 1e9);
+#ifdef COGS_LIFE_STAMPS
+    {
+        unsigned long long lf[8];
+        hipMemcpyFromSymbol(lf, HIP_SYMBOL(g_av_life), sizeof(lf));
+        printf("workgroup lifetime (wave 0, s_memtime ticks): %.0f on average over %llu workgroups\n", lf[1] ? (double)lf[0] / lf[1] : 0.0, lf[1]);
+    }
+#endif
 #ifdef COGS_ATTN_STAMPS
     unsigned long long st[8];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_attn_stamps), sizeof(st));
