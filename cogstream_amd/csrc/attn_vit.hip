@@ -403,7 +403,13 @@ __global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
 // (in-process A/B, tools/encoder_ab.py): with one workgroup per CU nothing computes during a workgroup's entry and exit
 // (13-15 % of its life, stamps below), and the two waves of a SIMD, now in one workgroup, are put back in step by every
 // tile barrier. Two 4-wave workgroups per CU it stays.
-template <int HD>
+// Round 6: R > 0 = the shape of the ragged end is compile-time. Every segment of the launch has the same length (p.uniform_len: one
+// video), nt >= 3 key tiles of which the last has NLB (1 or 2) 32-key blocks, and R = 3 + ((nt - 3) & 3) in 3..6 is the number of
+// tiles behind the four-tile main loop -- chosen so that nt - R is a multiple of 4: the first of them sits in ring slot 0, and ring
+// slots, block kinds, waits and the last tile requests of the end are constants instead of run-time tests on every sub-step. Eight
+// instantiations cover every length; R = 0 keeps the run-time form (segments of different lengths, fewer than 3 tiles). Same
+// arithmetic in the same order: bit-identical outputs (checksums of profiles/r6_attn_vit_ct_end_ab.txt, tests/test_gpu_ops.py).
+template <int HD, int R = 0, int NLB = 0>
 __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     constexpr int NT = 256, QB = 128, NS = 4, NW = 4;
     static_assert(HD % 8 == 0 && HD % 16 == 8 && HD < 96, "pad column HD must open a fresh 16-byte chunk inside the last k-step");
@@ -449,8 +455,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             qb = id % p.nqb; head = (id / p.nqb) % p.heads; seg = id / (p.nqb * p.heads);
         }
     }
-    const int qs = p.uniform_len > 0 ? seg * p.uniform_len : p.cu[seg];
-    const int qe = p.uniform_len > 0 ? qs + p.uniform_len : p.cu[seg + 1];
+    const int qs = (R > 0 || p.uniform_len > 0) ? seg * p.uniform_len : p.cu[seg];
+    const int qe = (R > 0 || p.uniform_len > 0) ? qs + p.uniform_len : p.cu[seg + 1];
     const int q0 = qs + qb * QB;
 #ifdef COGS_PIPE_STAMPS2
     asm volatile("" :: "s"(qs), "s"(qe));
@@ -784,6 +790,16 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #endif
     };
 
+    // the same with everything decided at compile time: WAIT1 = tile t + 2 exists (it may stay in flight), ISSUE = tile t + 3 exists
+    auto tile_head_ct = [&](const int t, auto slot_tag, auto wait1_tag, auto issue_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        if constexpr (decltype(wait1_tag)::value) wait_tiles(1); else wait_tiles(0);
+        __builtin_amdgcn_s_barrier();
+#ifndef ABL_NOLOAD
+        if constexpr (decltype(issue_tag)::value) issue_tile(t + 3, (SLOT + 3) & (NS - 1));
+#endif
+    };
+
     PSTAMP();      // 2: S(0) ready
 #ifndef AV_OLD_BRANCHES
     // A wave whose 32 query rows all lie past the segment end (the ragged last query block) only stages and keeps the barriers: it
@@ -797,7 +813,9 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     using Full = std::integral_constant<int, 1>;
 #ifndef AV_NO_UNROLL4
     // four tiles per trip: t is a multiple of 4 here, so tile t + i sits in ring slot i (compile-time LDS addresses)
-    for (; 2 * (t + 3) + 2 < nfull && t + 6 < nt; t += 4) {      // (t + 6 < nt: the tile the trip's last head requests exists)
+    // (R > 0: the trips end R tiles before the end; else: while blocks up to 2 t + 8 are full and t + 6 < nt, the tile the trip's
+    // last head requests)
+    for (; R > 0 ? t + R < nt : 2 * (t + 3) + 2 < nfull && t + 6 < nt; t += 4) {
 #ifdef ABL_NOCOMPUTE
 #define COGS_AV_ACTIVE false
 #elif defined(AV_OLD_BRANCHES)
@@ -825,6 +843,28 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #undef COGS_AV_TILE
     }
 #endif
+    if constexpr (R > 0) {
+        // the last R tiles, t = nt - R (a multiple of 4): tile t + I in ring slot I & 3; NB blocks in all, block E from the end is the
+        // last one (KIND 0), the one in front of it computes the last block's scores under its mask (KIND 3; a full last block
+        // passes the mask unchanged), every other one is an ordinary sub-step
+        constexpr int NB = 2 * R - (2 - NLB);
+#define COGS_AV_END_BLK(I, KB, SC, SN)                                                                                          \
+        if constexpr (NB - 1 - (2 * (I) + (KB)) >= 0) {                                                                          \
+            constexpr int E = NB - 1 - (2 * (I) + (KB));                                                                         \
+            substep(SC, SN, 2 * (t + (I)) + (KB), std::integral_constant<int, E == 0 ? 0 : E == 1 ? 3 : 1>{}, std::integral_constant<int, (I) & 3>{}); \
+        }
+#define COGS_AV_END(I)                                                                                                          \
+        if constexpr ((I) < R) {                                                                                                 \
+            tile_head_ct(t + (I), std::integral_constant<int, (I) & 3>{}, std::integral_constant<bool, ((I) + 2 < R)>{},         \
+                         std::integral_constant<bool, ((I) + 3 < R)>{});                                                         \
+            COGS_AV_END_BLK(I, 0, sa, sb)                                                                                        \
+            COGS_AV_END_BLK(I, 1, sb, sa)                                                                                        \
+        }
+        COGS_AV_END(0) COGS_AV_END(1) COGS_AV_END(2) COGS_AV_END(3) COGS_AV_END(4) COGS_AV_END(5)
+#undef COGS_AV_END
+#undef COGS_AV_END_BLK
+        t = nt;
+    }
     for (; 2 * t + 2 < nfull; ++t) {              // blocks 2t+1 and 2t+2 are full
         tile_head(t, std::integral_constant<int, -1>{}, std::false_type{});
 #ifndef ABL_NOCOMPUTE
@@ -927,7 +967,20 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     if (variant == 1 || a.ldk != a.ldv) { g_cogs_debug.attn_last_kernel = 2; hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p); }
     else {
         g_cogs_debug.attn_last_kernel = a.head_stride > 0 ? 8 : 3;
-        hipLaunchKernelGGL(attn_vit_pipe_kernel<72>, grid, dim3(256), 0, st, p);
+        // one video (all segments alike, 3 tiles or more): the instantiation whose ragged end has this length's shape
+        const int nt = (p.uniform_len + 63) >> 6;
+        const int r = (g_cogs_debug.attn_vit_len != 0 && p.uniform_len > 0 && nt >= 3) ? 3 + ((nt - 3) & 3) : 0;
+        const int nlb = p.uniform_len - 64 * (nt - 1) > 32 ? 2 : 1;
+#define COGS_AV_LAUNCH(R_, B_) hipLaunchKernelGGL((attn_vit_pipe_kernel<72, R_, B_>), grid, dim3(256), 0, st, p)
+        g_cogs_debug.attn_vit_last_end = r * 10 + (r ? nlb : 0);
+        switch (r * 10 + (r ? nlb : 0)) {
+            case 31: COGS_AV_LAUNCH(3, 1); break;   case 32: COGS_AV_LAUNCH(3, 2); break;
+            case 41: COGS_AV_LAUNCH(4, 1); break;   case 42: COGS_AV_LAUNCH(4, 2); break;
+            case 51: COGS_AV_LAUNCH(5, 1); break;   case 52: COGS_AV_LAUNCH(5, 2); break;
+            case 61: COGS_AV_LAUNCH(6, 1); break;   case 62: COGS_AV_LAUNCH(6, 2); break;
+            default: COGS_AV_LAUNCH(0, 0);
+        }
+#undef COGS_AV_LAUNCH
     }
     return COGS_LAUNCH_CHECK();
 }

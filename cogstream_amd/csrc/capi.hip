@@ -161,7 +161,7 @@ static bool cogs_debug_value_ok(const char* name, int64_t v) {
     struct Range { const char* name; int64_t lo, hi; };
     static const Range ranges[] = {
         {"gemm_wgs", 0, 256}, {"gemm_pad_pct", 100, 400}, {"gemm_group_m", 0, 64}, {"gemm_co_streams", 0, 8},
-        {"gemm_ring_cost_permille", 1, 4000}, {"gemv_small_n", 0, 1 << 30}, {"attn_vit", 0, 2}, {"attn_prio", 0, 2},
+        {"gemm_ring_cost_permille", 1, 4000}, {"gemv_small_n", 0, 1 << 30}, {"attn_vit", 0, 2}, {"attn_uniform_hint", 0, 1 << 20}, {"attn_prio", 0, 2},
         {"attn_nq", 0, 2}, {"vit_split_max", 0, INT64_MAX}, {"llm_split_keys", 0, 1 << 24}, {"km_row_groups", 0, 1 << 16},
     };
     for (const Range& r : ranges)
@@ -188,6 +188,7 @@ cogs_status cogs_debug_get(const char* name, int64_t* value) {
 #undef COGS_DBG_GET
     if (strcmp(name, "gemm_last_body") == 0) { *value = g_cogs_debug.gemm_last_body; return COGS_OK; }
     if (strcmp(name, "attn_last_kernel") == 0) { *value = g_cogs_debug.attn_last_kernel; return COGS_OK; }
+    if (strcmp(name, "attn_vit_last_end") == 0) { *value = g_cogs_debug.attn_vit_last_end; return COGS_OK; }
     return COGS_E_INVALID;
 }
 
@@ -199,7 +200,9 @@ const char* cogs_debug_list(void) {
         "gemm_last_body (read only): body the last cogs_gemm dispatched to -- 1 128x128, 2 256x128 ring, 3 K-tile ping-pong, "
         "4 whole-line ping-pong, 5 ping-pong + ring (split launch), 6 GEMV\n"
         "attn_last_kernel (read only): kernel of the last cogs_attention -- 1 general MFMA, 2 ViT unpipelined, 3 ViT pipelined, "
-        "4 single-token decode, 5 prompt LDS-DMA, 7 row-wise fp32, 8 ViT pipelined on head-major K/V\n";
+        "4 single-token decode, 5 prompt LDS-DMA, 7 row-wise fp32, 8 ViT pipelined on head-major K/V\n"
+        "attn_vit_last_end (read only): ragged end of the last pipelined ViT attention launch -- 10 x tiles behind the four-tile loop + "
+        "32-key blocks of the last tile (31 .. 62: compile-time shape), 0 the run-time form\n";
 }
 
 cogs_status cogs_create(int device, cogs_handle* out) {
@@ -275,6 +278,7 @@ cogs_status cogs_attention(cogs_stream stream, const cogs_attn_desc* d) {
     a.nsplit = d->nsplit > 1 ? d->nsplit : 1; a.ws = d->ws; a.ws_bytes = d->ws_bytes;
     a.q_prescaled = d->q_prescaled;
     a.head_stride = d->head_stride;
+    a.uniform_seqlen = (int)g_cogs_debug.attn_uniform_hint;      // 0 unless a test sets it (checked against q_len / max_seqlen by the kernel's launcher)
     return cogs_k_attention((hipStream_t)stream, a);
 }
 

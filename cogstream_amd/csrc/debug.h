@@ -36,6 +36,8 @@
     /* ---- attention (csrc/attn.hip, attn_vit.hip, attn_decode.hip) ---- */                                                \
     X(attn_vit, 2, "ViT block-diagonal attention: 2 pipelined LDS-DMA kernel, 1 unpipelined, 0 general kernel")            \
     X(attn_vit_early, 0, "1: pipelined ViT kernel issues tiles 1-2 before its first wait (the order before round 4)")       \
+    X(attn_vit_len, 1, "ViT attention: 0 the run-time form of the ragged end also for one-video launches (round 6: its shape as template parameters)") \
+    X(attn_uniform_hint, 0, "tests: > 0 = cogs_attention treats every cu_seqlens segment as exactly this many rows (the hint cogs_vit_encode derives from the grid itself)") \
     X(attn_decode, 1, "0: single-token attention through the general split-KV kernel")                                      \
     X(attn_combine32, 1, "split-KV combine: 1 one block per (head, 32-column slice), 8 loads in flight per thread; 0 one block per head") \
     X(attn_prefill_dma, 1, "0: Qwen2 prompt attention through the general register-staged kernel")                          \
@@ -59,5 +61,7 @@ struct CogsDebug {
     // decode (+ combine), 5 prompt LDS-DMA kernel, 7 row-wise fp32 kernel, 8 ViT pipelined, head-major K/V (6 and 9 were the archived
     // ping-pong / 64-rows-per-wave prompt kernels: tools/experiments/attn_prefill_variants.hip)
     std::atomic<long long> attn_last_kernel{0};
+    // ... and which ragged end the last pipelined ViT launch had: 10 R + blocks of the last tile (31 .. 62), 0 = the run-time form
+    std::atomic<long long> attn_vit_last_end{0};
 };
 extern CogsDebug g_cogs_debug;     // capi.hip

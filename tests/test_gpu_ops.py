@@ -261,6 +261,54 @@ def test_attention_vit_pipeline_edges(dev, heads, lens, data):
         assert (out[a:b] <= v[a:b].amax(0) + 2e-2).all() and (out[a:b] >= v[a:b].amin(0) - 2e-2).all()
 
 
+@pytest.mark.parametrize("seg", [129, 132, 160, 161, 176, 192, 193, 200, 240, 256, 257, 264, 308, 320, 336, 360, 384, 396, 440, 448,
+                                 500, 512, 576, 924, 1024])
+@pytest.mark.parametrize("layout", ["token", "head"])
+def test_attention_vit_compile_time_end_equals_run_time_end_bit_for_bit(dev, seg, layout):
+    """One video = every segment the same length: the pipelined ViT kernel is launched as the instantiation whose ragged end
+    (tiles behind the four-tile loop R = 3..6, 32-key blocks of the last tile 1 / 2) has that length's shape as template
+    parameters (csrc/attn_vit.hip, round 6). Lengths for all eight (R, blocks) pairs, last blocks of 1, 8, 31, 32 keys, exactly
+    full last tiles, the loop running 0 / 1 / 3 trips, both K/V layouts, growing scores on half the heads. The launch with the
+    hint must equal the launch without it (run-time end) bit for bit, and both the fp32 softmax."""
+    ops = _ops()
+    from cogstream_amd import _lib as L
+    heads, nseg, hd = 4, 5, 72
+    H, n = heads * hd, nseg * seg
+    g = torch.Generator().manual_seed(seg)
+    qkv = torch.randn(n, 3 * H, generator=g)
+    qkv[:, :H] *= LOG2E / math.sqrt(hd)
+    u = torch.randn(hd, generator=g)
+    u /= u.norm()
+    pos = torch.arange(seg, dtype=torch.float32).repeat(nseg)
+    for hh in range(0, heads, 2):
+        qkv[:, hh * hd:(hh + 1) * hd] += 1.5 * u
+        qkv[:, H + hh * hd:H + (hh + 1) * hd] += u * (pos[:, None] / 16.0)
+    qkv = qkv.bfloat16()
+    cu = torch.arange(nseg + 1, dtype=torch.int32) * seg
+    ref = _attn_ref(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], heads, heads, hd, cu=cu.long(), scale=math.log(2.0))
+    if layout == "head":
+        hm = qkv.view(n, 3, heads, hd).permute(1, 2, 0, 3).contiguous().to(dev)        # [which][head][row][hd]
+        run = lambda: ops.attention(hm[0], hm[1], hm[2], hq=heads, hkv=heads, head_dim=hd, cu_seqlens=cu.to(dev),
+                                    max_seqlen=seg, q_prescaled=True, head_major=True)
+    else:
+        gq = qkv.to(dev)
+        run = lambda: ops.attention(gq[:, :H], gq[:, H:2 * H], gq[:, 2 * H:], hq=heads, hkv=heads, head_dim=hd,
+                                    cu_seqlens=cu.to(dev), max_seqlen=seg, q_prescaled=True)
+    plain = run()
+    assert L.debug_get("attn_vit_last_end") == 0
+    with L.debug_switch("attn_uniform_hint", seg):
+        hinted = run()
+        nt = (seg + 63) // 64
+        assert L.debug_get("attn_vit_last_end") == 10 * (3 + ((nt - 3) & 3)) + (2 if seg - 64 * (nt - 1) > 32 else 1)
+        with L.debug_switch("attn_vit_len", 0):
+            hinted_rt = run()
+            assert L.debug_get("attn_vit_last_end") == 0
+    assert torch.equal(plain, hinted) and torch.equal(plain, hinted_rt)
+    out = hinted.float().cpu()
+    err = (out - ref).abs().view(n, heads, hd).amax(2) / ref.abs().view(n, heads, hd).amax(2).clamp_min(1e-3)
+    assert float(err.max()) < 3e-2, (float(err.max()), int(err.argmax()) // heads)
+
+
 @pytest.mark.parametrize("S,pos0", [(200, 0), (130, 77), (1, 300), (1, 5000)])
 def test_attention_prescaled_q_causal_gqa(dev, S, pos0):
     ops = _ops()

@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
         a.K = qkv + L * H; a.V = qkv + 2 * L * H; a.ldq = a.ldk = a.ldv = hd; a.head_stride = L * hd;
     }
     a.q_len = a.kv_len = (int)L; a.hq = a.hkv = heads; a.head_dim = hd; a.q_prescaled = 1;
+    if (argc > 4) g_cogs_debug.attn_vit_len = atoi(argv[4]);      // 0: the run-time-length kernel for every frame size
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) cogs_k_attention_vit(0, a);
     hipDeviceSynchronize();
