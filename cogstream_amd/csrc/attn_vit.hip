@@ -404,10 +404,11 @@ __global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
 // (13-15 % of its life, stamps below), and the two waves of a SIMD, now in one workgroup, are put back in step by every
 // tile barrier. Two 4-wave workgroups per CU it stays.
 // Round 6: R > 0 = the shape of the ragged end is compile-time. Every segment of the launch has the same length (p.uniform_len: one
-// video), nt >= 3 key tiles of which the last has NLB (1 or 2) 32-key blocks, and R = 3 + ((nt - 3) & 3) in 3..6 is the number of
-// tiles behind the four-tile main loop -- chosen so that nt - R is a multiple of 4: the first of them sits in ring slot 0, and ring
-// slots, block kinds, waits and the last tile requests of the end are constants instead of run-time tests on every sub-step. Eight
-// instantiations cover every length; R = 0 keeps the run-time form (segments of different lengths, fewer than 3 tiles). Same
+// video), nt >= 4 key tiles of which the last has NLB (1 or 2) 32-key blocks, and R = 4 + ((nt - 4) & 3) in 4..7 is the number of
+// tiles behind the four-tile main loop -- chosen so that nt - R is a multiple of 4 (the first of them sits in ring slot 0) and that
+// every tile the main loop requests is a full one (the last tile is requested from the end): ring slots, block kinds, waits, the
+// tile requests of the end AND the ragged-tile test of every request are constants instead of run-time tests next to the MFMAs.
+// Eight instantiations cover every length; R = 0 keeps the run-time form (segments of different lengths, fewer than 4 tiles). Same
 // arithmetic in the same order: bit-identical outputs (checksums of profiles/r6_attn_vit_ct_end_ab.txt, tests/test_gpu_ops.py).
 template <int HD, int R = 0, int NLB = 0>
 __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
@@ -484,9 +485,18 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 
     // DMA pieces: piece j (0..8) of a matrix covers chunks 64j..64j+63 of the tile image (chunk c = row c / 9, 16-byte
     // column c % 9). Wave w issues pieces w, w + NW, ... < 8 of K and of V (two each with 4 waves, one with 8); piece 8 of
-    // K goes to wave 0, of V to wave 1.
+    // K goes to wave 0, of V to wave 1 (-DAV_WAVE_NINTH, the form up to round 5) -- round 6: the ninth pieces go out in HALVES, one
+    // half per wave (K lanes 0-31: wave 0, K lanes 32-63: wave 1, V: waves 2 and 3) under a half EXEC mask: every wave issues the
+    // same 2 NPI + 1 requests per tile, selected by scalar moves instead of two wave-dependent branches behind the tile's barrier,
+    // and the counted waits are exact for all four waves.
     constexpr int NPI = 8 / NW;                                  // regular pieces per matrix and wave
+#ifdef AV_WAVE_NINTH
     const int n_own = 2 * NPI + (wid < 2 ? 1 : 0);               // this wave's DMA instructions per tile
+#else
+    const int n_own = 2 * NPI + 1;
+    const unsigned long long ninth_exec = (wid & 1) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+    const bool ninth_v = wid >= 2;
+#endif
     int pc_row[NPI + 1], pc_off[NPI + 1];                        // per-lane row and byte offset of the wave's pieces
 #pragma unroll
     for (int i = 0; i < NPI + 1; ++i) {
@@ -516,8 +526,9 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     const bf16_t* k_next = p.K + (long)qs * p.ldk + head * p.head_stride;
     const bf16_t* v_next = p.V + (long)qs * p.ldv + head * p.head_stride;
     const long tile_step = 64 * p.ldk;                           // elements; ldk == ldv
-    auto issue_tile = [&](int t, int slot) {                     // slot = t & (NS - 1), a constant in the unrolled loop
-        const int valid = qe - (qs + t * 64);                    // >= 1
+    auto issue_tile_g = [&](int t, int slot, auto full_tag) {     // slot = t & (NS - 1), a constant in the unrolled loop
+        constexpr bool KNOWN_FULL = decltype(full_tag)::value;   // the caller knows the tile has all 64 rows: no test (R > 0 forms)
+        const int valid = KNOWN_FULL ? 64 : qe - (qs + t * 64);  // >= 1
         const bf16_t* kb = uniform_ptr(k_next);
         const bf16_t* vb = uniform_ptr(v_next);
         k_next += tile_step; v_next += tile_step;
@@ -534,9 +545,22 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
             dma16(kb, off[i], st + (wid + NW * i) * 1024);
             dma16(vb, off[i], st + TILE + (wid + NW * i) * 1024);
         }
+#ifdef AV_ABL_NO_NINTH       // timing experiment (tools/attn_abl.sh): what do the ninth pieces cost? (wrong results)
+#elif defined(AV_WAVE_NINTH)
         if (wid == 0) dma16(kb, off[NPI], st + 8 * 1024);
         if (wid == 1) dma16(vb, off[NPI], st + TILE + 8 * 1024);
+#else
+        // EXEC is all ones here (wave-uniform control flow throughout the kernel) and is put back to all ones
+        const unsigned long long nx = ninth_exec;                // (copies: an asm operand alone does not capture in a generic lambda)
+        const bf16_t* const nb = ninth_v ? vb : kb;
+        const unsigned nl = st + (ninth_v ? TILE : 0) + 8 * 1024;
+        const int no = off[NPI];
+        asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
+                     :: "s"(nx), "s"(nl), "v"(no), "s"(nb) : "memory");
+#endif
     };
+    auto issue_tile = [&](int t, int slot) { issue_tile_g(t, slot, std::false_type{}); };      // ragged or not: tested
+    using FirstTilesFull = std::integral_constant<bool, (R > 0)>;                               // R > 0: nt >= 4
     // this wave's pieces of every tile but the `newer` most recently issued ones have landed (n_own = 2 NPI or 2 NPI + 1)
 #ifdef AV_OLD_BRANCHES      // A/B builds (tools/attn_abl.sh): the round-5 control flow of the tile loop
     auto wait_tiles = [&](int newer) {
@@ -550,10 +574,15 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     // the tile loop loses a wave-dependent branch in front of its barrier (a scalar branch next to an MFMA block costs percent:
     // profiles/r6_gemm_idle_branch_ab.txt, r6_prefill_attn_branches_ab.txt).
     (void)n_own;
+#ifdef AV_WAVE_NINTH
+    constexpr int PER_TILE = 2 * NPI;
+#else
+    constexpr int PER_TILE = 2 * NPI + 1;      // every wave alike: exact
+#endif
     auto wait_tiles = [&](int newer) {
         if (newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NPI) : "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER_TILE) : "memory");
     };
 #endif
 
@@ -561,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     // Round 5: tile 0 goes out HERE, as soon as its addresses exist -- in front of the ~800 cycles of per-lane read offsets,
     // accumulator zeroing and fragment-address setup below, which then run under the memory round trip instead of in front of it
     // (inline-asm DMA is a scheduling boundary for hipcc: where the statement stands is where the instruction goes).
-    issue_tile(0, 0);
+    issue_tile_g(0, 0, FirstTilesFull{});
 #endif
     // per-lane LDS read offsets inside a stage. K: lane (key r32, k-half h) reads 16 bytes at column 32 ks + 16 h; in
     // the last k-step half 1 is the pad chunk -> constant [1, 0 x7]
@@ -657,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     PSTAMP();      // Q loads issued
 #endif
 #ifdef AV_LATE_ISSUE
-    issue_tile(0, 0);
+    issue_tile_g(0, 0, FirstTilesFull{});
 #endif
     // round 4: only Q and tile 0 go out before the first wait (10 vector-memory instructions per wave instead of 18: the
     // CU's vector-memory path takes one 1 KiB piece per ~60-115 cycles, so the 8 pieces of tiles 1 and 2 used to stand
@@ -665,8 +694,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     // the tile loop see the same queue as before. (p.early_prefetch: the old order, for A/B runs)
     const bool EARLY = p.early_prefetch != 0;
     if (EARLY) {
-        if (nt > 1) issue_tile(1, 1);
-        if (nt > 2) issue_tile(2, 2);
+        if (R > 0 || nt > 1) issue_tile_g(1, 1, FirstTilesFull{});
+        if (R > 0 || nt > 2) issue_tile_g(2, 2, FirstTilesFull{});
     }
 #ifdef COGS_PIPE_STAMPS2
     PSTAMP();      // tiles issued
@@ -678,8 +707,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     PSTAMP();      // 1: Q and tile 0 landed
     __builtin_amdgcn_s_barrier();
     if (!EARLY) {
-        if (nt > 1) issue_tile(1, 1);
-        if (nt > 2) issue_tile(2, 2);
+        if (R > 0 || nt > 1) issue_tile_g(1, 1, FirstTilesFull{});
+        if (R > 0 || nt > 2) issue_tile_g(2, 2, FirstTilesFull{});
     }
     f32x16 sa, sb;
     u32x4 kf[KS];                                                     // K fragments of the NEXT block to be multiplied
@@ -782,7 +811,8 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         __builtin_amdgcn_s_barrier();     // K(t+1), V(t) visible to all; slot of tile t-1 no longer read by anyone
         PHT(h2);
 #ifndef ABL_NOLOAD
-        if (STEADY || t + 3 < nt) issue_tile(t + 3, SLOT >= 0 ? (SLOT + 3) & (NS - 1) : (t + 3) & (NS - 1));
+        if constexpr (STEADY && R > 0) issue_tile_g(t + 3, (SLOT + 3) & (NS - 1), std::true_type{});      // a full tile by the choice of R
+        else if (STEADY || t + 3 < nt) issue_tile(t + 3, SLOT >= 0 ? (SLOT + 3) & (NS - 1) : (t + 3) & (NS - 1));
 #endif
         PHT(h3);
 #ifdef COGS_PHASE_STAMPS
@@ -791,12 +821,15 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     };
 
     // the same with everything decided at compile time: WAIT1 = tile t + 2 exists (it may stay in flight), ISSUE = tile t + 3 exists
+    // (ISSUE 2: ... and is known to be full, i.e. not the segment's last tile)
     auto tile_head_ct = [&](const int t, auto slot_tag, auto wait1_tag, auto issue_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int ISSUE = decltype(issue_tag)::value;
         if constexpr (decltype(wait1_tag)::value) wait_tiles(1); else wait_tiles(0);
         __builtin_amdgcn_s_barrier();
 #ifndef ABL_NOLOAD
-        if constexpr (decltype(issue_tag)::value) issue_tile(t + 3, (SLOT + 3) & (NS - 1));
+        if constexpr (ISSUE == 2) issue_tile_g(t + 3, (SLOT + 3) & (NS - 1), std::true_type{});
+        else if constexpr (ISSUE == 1) issue_tile(t + 3, (SLOT + 3) & (NS - 1));
 #endif
     };
 
@@ -856,15 +889,15 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #define COGS_AV_END(I)                                                                                                          \
         if constexpr ((I) < R) {                                                                                                 \
             tile_head_ct(t + (I), std::integral_constant<int, (I) & 3>{}, std::integral_constant<bool, ((I) + 2 < R)>{},         \
-                         std::integral_constant<bool, ((I) + 3 < R)>{});                                                         \
+                         std::integral_constant<int, ((I) + 3 < R - 1) ? 2 : ((I) + 3 < R) ? 1 : 0>{});                          \
             COGS_AV_END_BLK(I, 0, sa, sb)                                                                                        \
             COGS_AV_END_BLK(I, 1, sb, sa)                                                                                        \
         }
-        COGS_AV_END(0) COGS_AV_END(1) COGS_AV_END(2) COGS_AV_END(3) COGS_AV_END(4) COGS_AV_END(5)
+        COGS_AV_END(0) COGS_AV_END(1) COGS_AV_END(2) COGS_AV_END(3) COGS_AV_END(4) COGS_AV_END(5) COGS_AV_END(6)
 #undef COGS_AV_END
 #undef COGS_AV_END_BLK
-        t = nt;
     }
+    if constexpr (R == 0)
     for (; 2 * t + 2 < nfull; ++t) {              // blocks 2t+1 and 2t+2 are full
         tile_head(t, std::integral_constant<int, -1>{}, std::false_type{});
 #ifndef ABL_NOCOMPUTE
@@ -882,6 +915,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int tl_n = 0;
 #endif
+    if constexpr (R == 0)
     for (; t < nt; ++t) {                         // the ragged end: block kinds decided at run time (wave-uniform)
         unsigned long long q0_ = 0, q1_ = 0;
         PHT(q0_);
@@ -967,17 +1001,17 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     if (variant == 1 || a.ldk != a.ldv) { g_cogs_debug.attn_last_kernel = 2; hipLaunchKernelGGL(attn_vit_kernel<72>, grid, dim3(256), 0, st, p); }
     else {
         g_cogs_debug.attn_last_kernel = a.head_stride > 0 ? 8 : 3;
-        // one video (all segments alike, 3 tiles or more): the instantiation whose ragged end has this length's shape
+        // one video (all segments alike, 4 tiles or more): the instantiation whose ragged end has this length's shape
         const int nt = (p.uniform_len + 63) >> 6;
-        const int r = (g_cogs_debug.attn_vit_len != 0 && p.uniform_len > 0 && nt >= 3) ? 3 + ((nt - 3) & 3) : 0;
+        const int r = (g_cogs_debug.attn_vit_len != 0 && p.uniform_len > 0 && nt >= 4) ? 4 + ((nt - 4) & 3) : 0;
         const int nlb = p.uniform_len - 64 * (nt - 1) > 32 ? 2 : 1;
 #define COGS_AV_LAUNCH(R_, B_) hipLaunchKernelGGL((attn_vit_pipe_kernel<72, R_, B_>), grid, dim3(256), 0, st, p)
         g_cogs_debug.attn_vit_last_end = r * 10 + (r ? nlb : 0);
         switch (r * 10 + (r ? nlb : 0)) {
-            case 31: COGS_AV_LAUNCH(3, 1); break;   case 32: COGS_AV_LAUNCH(3, 2); break;
             case 41: COGS_AV_LAUNCH(4, 1); break;   case 42: COGS_AV_LAUNCH(4, 2); break;
             case 51: COGS_AV_LAUNCH(5, 1); break;   case 52: COGS_AV_LAUNCH(5, 2); break;
             case 61: COGS_AV_LAUNCH(6, 1); break;   case 62: COGS_AV_LAUNCH(6, 2); break;
+            case 71: COGS_AV_LAUNCH(7, 1); break;   case 72: COGS_AV_LAUNCH(7, 2); break;
             default: COGS_AV_LAUNCH(0, 0);
         }
 #undef COGS_AV_LAUNCH

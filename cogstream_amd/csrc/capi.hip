@@ -202,7 +202,7 @@ const char* cogs_debug_list(void) {
         "attn_last_kernel (read only): kernel of the last cogs_attention -- 1 general MFMA, 2 ViT unpipelined, 3 ViT pipelined, "
         "4 single-token decode, 5 prompt LDS-DMA, 7 row-wise fp32, 8 ViT pipelined on head-major K/V\n"
         "attn_vit_last_end (read only): ragged end of the last pipelined ViT attention launch -- 10 x tiles behind the four-tile loop + "
-        "32-key blocks of the last tile (31 .. 62: compile-time shape), 0 the run-time form\n";
+        "32-key blocks of the last tile (41 .. 72: compile-time shape), 0 the run-time form\n";
 }
 
 cogs_status cogs_create(int device, cogs_handle* out) {

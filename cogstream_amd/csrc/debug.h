@@ -61,7 +61,7 @@ struct CogsDebug {
     // decode (+ combine), 5 prompt LDS-DMA kernel, 7 row-wise fp32 kernel, 8 ViT pipelined, head-major K/V (6 and 9 were the archived
     // ping-pong / 64-rows-per-wave prompt kernels: tools/experiments/attn_prefill_variants.hip)
     std::atomic<long long> attn_last_kernel{0};
-    // ... and which ragged end the last pipelined ViT launch had: 10 R + blocks of the last tile (31 .. 62), 0 = the run-time form
+    // ... and which ragged end the last pipelined ViT launch had: 10 R + blocks of the last tile (41 .. 72), 0 = the run-time form
     std::atomic<long long> attn_vit_last_end{0};
 };
 extern CogsDebug g_cogs_debug;     // capi.hip

@@ -266,7 +266,7 @@ def test_attention_vit_pipeline_edges(dev, heads, lens, data):
 @pytest.mark.parametrize("layout", ["token", "head"])
 def test_attention_vit_compile_time_end_equals_run_time_end_bit_for_bit(dev, seg, layout):
     """One video = every segment the same length: the pipelined ViT kernel is launched as the instantiation whose ragged end
-    (tiles behind the four-tile loop R = 3..6, 32-key blocks of the last tile 1 / 2) has that length's shape as template
+    (tiles behind the four-tile loop R = 4..7, 32-key blocks of the last tile 1 / 2) has that length's shape as template
     parameters (csrc/attn_vit.hip, round 6). Lengths for all eight (R, blocks) pairs, last blocks of 1, 8, 31, 32 keys, exactly
     full last tiles, the loop running 0 / 1 / 3 trips, both K/V layouts, growing scores on half the heads. The launch with the
     hint must equal the launch without it (run-time end) bit for bit, and both the fp32 softmax."""
@@ -299,7 +299,8 @@ def test_attention_vit_compile_time_end_equals_run_time_end_bit_for_bit(dev, seg
     with L.debug_switch("attn_uniform_hint", seg):
         hinted = run()
         nt = (seg + 63) // 64
-        assert L.debug_get("attn_vit_last_end") == 10 * (3 + ((nt - 3) & 3)) + (2 if seg - 64 * (nt - 1) > 32 else 1)
+        want = 10 * (4 + ((nt - 4) & 3)) + (2 if seg - 64 * (nt - 1) > 32 else 1) if nt >= 4 else 0
+        assert L.debug_get("attn_vit_last_end") == want
         with L.debug_switch("attn_vit_len", 0):
             hinted_rt = run()
             assert L.debug_get("attn_vit_last_end") == 0
