@@ -517,6 +517,9 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     // (M0 is a reserved register for hipcc: it never keeps a value there across statements and sets it right in front
     // of its own uses, so writing it here needs no clobber -- naming it in the clobber list only draws a warning)
     auto dma16 = [&](const bf16_t* base, int off_bytes, unsigned lds) {
+#ifdef AV_ABL_NORESCALE      // (in this ablation build hipcc loses track of the address being wave-uniform)
+        lds = __builtin_amdgcn_readfirstlane(lds);
+#endif
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                      :: "s"(lds), "v"(off_bytes), "s"(base) : "memory");
     };
@@ -553,7 +556,11 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         // EXEC is all ones here (wave-uniform control flow throughout the kernel) and is put back to all ones
         const unsigned long long nx = ninth_exec;                // (copies: an asm operand alone does not capture in a generic lambda)
         const bf16_t* const nb = ninth_v ? vb : kb;
+#ifdef AV_ABL_NORESCALE
+        const unsigned nl = __builtin_amdgcn_readfirstlane(st + (ninth_v ? TILE : 0) + 8 * 1024);
+#else
         const unsigned nl = st + (ninth_v ? TILE : 0) + 8 * 1024;
+#endif
         const int no = off[NPI];
         asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
                      :: "s"(nx), "s"(nl), "v"(no), "s"(nb) : "memory");
