@@ -37,6 +37,7 @@ struct VitAttnArgs {
     long ldq, ldk, ldv, ldo;   // elements
     const int* cu;             // [nseg + 1]
     int nseg, heads, nqb;      // grid = nseg * heads * nqb workgroups (nqb = 128-row query blocks of the longest segment)
+    int xcd_order;             // 1: grid (8 nqb, heads / 8, nseg), head = 8 y + (x & 7); 0: grid (nqb, heads, nseg)
     int early_prefetch;        // pipe kernel prologue: tiles 1 and 2 issued before (1) / behind (0) the first wait
     long head_stride;          // elements from head h to head h + 1 of Q / K / V: HD for the token-major layout (ld* = row stride of
                                // the fused qkv buffer), rows * HD for the head-major one (ld* = HD: a head's rows back to back, so a
@@ -86,18 +87,13 @@ __global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
     // (frame, head) all read the same K/V: keep them on ONE XCD and close in time -- id = (group * nqb + qb) * 8 + slot with
     // (frame, head) = group * 8 + slot. (The plain (qb, head, frame) grid put the 8 q-blocks of a (frame, head) on 8
     // different XCDs at the same moment: every L2 fetched the same K/V from the fabric, 8x the traffic.)
+    // The grid is 3-D so that nothing is divided here (round 6: the three signed divisions of the linear form were ~150 vector
+    // instructions at the head of every workgroup's critical path, in front of its first address). heads % 8 == 0 (p.xcd_order):
+    // x = query block * 8 + slot, y = head / 8, z = segment, head = 8 y + slot -- the linear dispatch order is
+    // ((segment, head / 8), query block, slot), i.e. the same (frame, head) -> XCD map as described above; else plain (qb, head, seg).
     int seg, head, qb;
-    {
-        const int nhf = p.nseg * p.heads, id = blockIdx.x;
-        if (nhf % 8 == 0) {
-            const int slot = id & 7, rest = id >> 3;
-            qb = rest % p.nqb;
-            const int hf = (rest / p.nqb) * 8 + slot;
-            seg = hf / p.heads; head = hf % p.heads;
-        } else {
-            qb = id % p.nqb; head = (id / p.nqb) % p.heads; seg = id / (p.nqb * p.heads);
-        }
-    }
+    if (p.xcd_order) { qb = blockIdx.x >> 3; head = blockIdx.y * 8 + (blockIdx.x & 7); seg = blockIdx.z; }
+    else { qb = blockIdx.x; head = blockIdx.y; seg = blockIdx.z; }
     const int qs = p.cu[seg], qe = p.cu[seg + 1];
     const int q0 = qs + qb * QB;
     if (q0 >= qe) return;
@@ -444,18 +440,9 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
     PSTAMP();      // 0: kernel entry
     unsigned long long life0 = 0, life1 = 0;
     LIFE_NOW(life0);
-    int seg, head, qb;
-    {
-        const int nhf = p.nseg * p.heads, id = blockIdx.x;      // XCD-aware order, see attn_vit_kernel
-        if (nhf % 8 == 0) {
-            const int slot = id & 7, rest = id >> 3;
-            qb = rest % p.nqb;
-            const int hf = (rest / p.nqb) * 8 + slot;
-            seg = hf / p.heads; head = hf % p.heads;
-        } else {
-            qb = id % p.nqb; head = (id / p.nqb) % p.heads; seg = id / (p.nqb * p.heads);
-        }
-    }
+    int seg, head, qb;                                           // XCD-aware 3-D grid, see attn_vit_kernel
+    if (p.xcd_order) { qb = blockIdx.x >> 3; head = blockIdx.y * 8 + (blockIdx.x & 7); seg = blockIdx.z; }
+    else { qb = blockIdx.x; head = blockIdx.y; seg = blockIdx.z; }
     const int qs = (R > 0 || p.uniform_len > 0) ? seg * p.uniform_len : p.cu[seg];
     const int qe = (R > 0 || p.uniform_len > 0) ? qs + p.uniform_len : p.cu[seg + 1];
     const int q0 = qs + qb * QB;
@@ -1000,8 +987,9 @@ int cogs_k_attention_vit(hipStream_t st, const CogsAttn& a) {
     p.head_stride = a.head_stride > 0 ? a.head_stride : 72;
     if (a.head_stride > 0 && (a.ldq != 72 || a.ldk != 72 || a.ldv != 72)) return COGS_E_INVALID;
     p.uniform_len = (a.uniform_seqlen > 0 && (long)a.uniform_seqlen * a.nseg == a.q_len && a.uniform_seqlen == a.max_seqlen) ? a.uniform_seqlen : 0;
-    if ((long)p.nseg * p.heads * p.nqb > 0x7fffffffL) return COGS_E_INVALID;
-    dim3 grid(p.nseg * p.heads * p.nqb);
+    if (p.nseg > 65535 || p.heads > 65535 || (long)p.nqb * 8 > 0x7fffffffL) return COGS_E_INVALID;
+    p.xcd_order = p.heads % 8 == 0;
+    const dim3 grid = p.xcd_order ? dim3(p.nqb * 8, p.heads / 8, p.nseg) : dim3(p.nqb, p.heads, p.nseg);
     const int variant = (int)g_cogs_debug.attn_vit;     // 1: unpipelined (A/B runs)
     const int env_early = (int)g_cogs_debug.attn_vit_early;
     p.early_prefetch = env_early;
