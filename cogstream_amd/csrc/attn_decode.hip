@@ -28,7 +28,7 @@ struct DecodeAttnArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* V;
     long ldk, ldv;                 // elements
     int kend;                      // keys 0 .. kend-1 are visible
-    int hq, hkv, nsplit;
+    int hq, hkv, nsplit, gsz;
     float* part_o;                 // [nsplit][hq][128] unnormalised, relative to part_ml[..][0]
     float* part_ml;                // [nsplit][hq][2] (running max in log2 units, sum)
 };
@@ -58,11 +58,13 @@ __global__ __launch_bounds__(256, 1) void attn_decode_kernel(DecodeAttnArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
     const int split = blockIdx.x, kvh = blockIdx.y;
-    const int gsz = p.hq / p.hkv;
+    const int gsz = p.gsz;                                       // hq / hkv, divided on the host
 
-    const int nt_all = (p.kend + 63) >> 6;
-    const int t_begin = (int)((long)nt_all * split / p.nsplit);
-    const int t_end = (int)((long)nt_all * (split + 1) / p.nsplit);
+    // (unsigned 32-bit: tiles x splits is far below 2^32, checked by the launcher; the signed 64-bit form was two ~100-instruction
+    // divisions at the head of a 10 us kernel)
+    const unsigned nt_all = (unsigned)(p.kend + 63) >> 6;
+    const int t_begin = (int)(nt_all * (unsigned)split / (unsigned)p.nsplit);
+    const int t_end = (int)(nt_all * (unsigned)(split + 1) / (unsigned)p.nsplit);
 
     // Q fragments (B operand of S^T = K.Q^T): lane (q = li, g) holds Q[head kvh*gsz + li][32s + 8g .. +7]
     bf16x8 qf[4];
@@ -195,7 +197,8 @@ int cogs_k_attention_decode(hipStream_t st, const CogsAttn& a, float* part_o, fl
     p.ldk = a.ldk; p.ldv = a.ldv;
     p.kend = a.causal ? (a.q_pos0 + 1 < a.kv_len ? a.q_pos0 + 1 : a.kv_len) : a.kv_len;
     if (p.kend < 1) return COGS_E_INVALID;
-    p.hq = a.hq; p.hkv = a.hkv; p.nsplit = a.nsplit;
+    p.hq = a.hq; p.hkv = a.hkv; p.nsplit = a.nsplit; p.gsz = a.hq / a.hkv;
+    if ((long)((p.kend + 63) >> 6) * (a.nsplit + 1) > 0x7fffffffL) return COGS_E_INVALID;
     p.part_o = part_o; p.part_ml = part_ml;
     hipLaunchKernelGGL(attn_decode_kernel, dim3(a.nsplit, a.hkv), dim3(256), 0, st, p);
     return COGS_LAUNCH_CHECK();
