@@ -61,6 +61,8 @@ __device__ unsigned long long g_av_life[8];
 #define LIFE_NOW(v) do {} while (0)
 #define LIFE_ADD(i, v) do {} while (0)
 #endif
+// the workgroup whose stamps are kept is named by its place in the dispatch order (the grid is 3-D since round 6)
+#define COGS_AV_LINEAR_ID ((int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x))
 #ifdef COGS_ATTN_STAMPS   // where does a tile's time go, wave 0 of one workgroup
 #define STAMP(acc_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - st_prev; st_prev = now_; } while (0)
 #else
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_kernel(VitAttnArgs p) {
 #endif
     }
 #ifdef COGS_ATTN_STAMPS
-    if (blockIdx.x == 1234 && tid == 0) {
+    if (COGS_AV_LINEAR_ID == 1234 && tid == 0) {
         g_attn_stamps[0] = st_bar; g_attn_stamps[1] = st_stage; g_attn_stamps[2] = st_qk; g_attn_stamps[3] = st_sm;
         g_attn_stamps[4] = st_pv; g_attn_stamps[5] = full_tiles;
     }
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #endif
     }
 #ifdef COGS_PHASE_STAMPS
-    if (blockIdx.x == 3000 && tid == 0) { for (int i = 0; i < 8; ++i) g_attn_stamps[i] = ph_acc[i]; }
+    if (COGS_AV_LINEAR_ID == 3000 && tid == 0) { for (int i = 0; i < 8; ++i) g_attn_stamps[i] = ph_acc[i]; }
 #endif
     PSTAMP();      // 3: main loop done
 #ifdef COGS_PHASE_STAMPS
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
         }
     }
 #ifdef COGS_PHASE_STAMPS
-    if (blockIdx.x == 3000 && tid == 0) { for (int i = 0; i < 8; ++i) g_tail_stamps[i] = tl_acc[i]; }
+    if (COGS_AV_LINEAR_ID == 3000 && tid == 0) { for (int i = 0; i < 8; ++i) g_tail_stamps[i] = tl_acc[i]; }
 #endif
     PSTAMP();      // 4: tail done
     if (!wave_active) return;
@@ -969,7 +971,7 @@ __global__ __launch_bounds__(256, 2) void attn_vit_pipe_kernel(VitAttnArgs p) {
 #ifdef COGS_PIPE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PSTAMP();      // 5: O stored
-    if (blockIdx.x == 3000 && tid == 0) { for (int i = 0; i < 8; ++i) g_attn_stamps[i] = ps_t[i]; }
+    if (COGS_AV_LINEAR_ID == 3000 && tid == 0) { for (int i = 0; i < 8; ++i) g_attn_stamps[i] = ps_t[i]; }
 #endif
 }
 
